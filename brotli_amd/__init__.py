@@ -1,0 +1,150 @@
+"""brotli_amd -- host-side mirror of the reference's decode interface on top of
+libyeast_mi355x.so (HIP kernels for MI355X / gfx950).
+
+The functions keep the names, argument meaning and error behaviour of the
+reference interface they stand for (paths relative to /root/reference):
+
+  yeast(source, expected=None)    yeast.h:25 / yeast.c:1353  -> (rc, out, used)
+  yeast_batch(streams, check)     a loop over yeast.h:25 such as juxt.c:77-93
+  crc32c / xxh32 / xxh64          crc32c.c:258, xxhash.c:365, xxhash.c:505
+
+There is no CPU decode path: importing works anywhere (so the CPU test tier
+can check that the library loads and exports its symbols), but every compute
+call raises RuntimeError when the HIP library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyeast_mi355x.so")
+
+CHECK_NONE, CHECK_CRC32C, CHECK_XXH32, CHECK_XXH64 = 0, 1, 2, 3
+SRC_PAD = 32
+
+EXPORTS = [  # every symbol include/yeast.h and include/yeast_batch.h declare
+    "yeast", "yeast_verbosity", "yeast_batch", "yeast_batch_device", "yeast_check_device",
+    "crc32c", "XXH32", "XXH64", "yeast_last_error", "yeast_device_count", "yeast_debug_table",
+]
+
+
+class Record(ctypes.Structure):
+    """yeast_record of include/yeast_batch.h (32 bytes)."""
+    _fields_ = [("rc", ctypes.c_int32), ("flags", ctypes.c_uint32), ("got", ctypes.c_uint64),
+                ("used", ctypes.c_uint64), ("check", ctypes.c_uint64)]
+
+
+_lib = None
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [ctypes.c_void_p]
+
+
+def lib() -> ctypes.CDLL:
+    """Load libyeast_mi355x.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.yeast.restype = ctypes.c_int
+        L.yeast.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
+                            ctypes.POINTER(ctypes.c_size_t), ctypes.c_int]
+        L.yeast_batch.restype = ctypes.c_int
+        L.yeast_batch.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                  ctypes.POINTER(ctypes.c_int), ctypes.c_uint, ctypes.POINTER(ctypes.c_uint64)]
+        L.yeast_batch_device.restype = ctypes.c_int
+        L.yeast_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int,
+                                         ctypes.c_void_p]
+        L.yeast_check_device.restype = ctypes.c_int
+        L.yeast_check_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.c_uint, ctypes.c_void_p]
+        L.crc32c.restype = ctypes.c_uint32
+        L.crc32c.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+        L.XXH32.restype = ctypes.c_uint
+        L.XXH32.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint]
+        L.XXH64.restype = ctypes.c_ulonglong
+        L.XXH64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_ulonglong]
+        L.yeast_last_error.restype = ctypes.c_char_p
+        L.yeast_device_count.restype = ctypes.c_int
+        L.yeast_debug_table.restype = ctypes.c_void_p
+        L.yeast_debug_table.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+        _lib = L
+    return _lib
+
+
+def _err(what: str) -> RuntimeError:
+    return RuntimeError("%s: %s" % (what, lib().yeast_last_error().decode() or "GPU path unavailable"))
+
+
+def yeast(source: bytes, expected: Optional[bytes] = None) -> Tuple[int, Optional[bytes], int, int]:
+    """yeast.h:25.  Decode mode (expected is None): returns (rc, output, got, used).
+    Compare mode: returns (rc, None, got, used) where got is how far the output matched."""
+    L = lib()
+    src = ctypes.create_string_buffer(source, max(len(source), 1))
+    ln = ctypes.c_size_t(len(source))
+    if expected is None:
+        dest = ctypes.c_void_p(None)
+        got = ctypes.c_size_t(0)
+        rc = L.yeast(ctypes.byref(dest), ctypes.byref(got), src, ctypes.byref(ln), 0)
+        if rc < 0:
+            raise _err("yeast")
+        out = ctypes.string_at(dest.value, got.value) if dest.value else b""
+        if dest.value:
+            _libc.free(dest)
+        return rc, out, got.value, ln.value
+    keep = ctypes.create_string_buffer(expected, max(len(expected), 1))
+    dest = ctypes.c_void_p(ctypes.addressof(keep))
+    got = ctypes.c_size_t(len(expected))
+    rc = L.yeast(ctypes.byref(dest), ctypes.byref(got), src, ctypes.byref(ln), 1)
+    if rc < 0:
+        raise _err("yeast")
+    return rc, None, got.value, ln.value
+
+
+def yeast_batch(streams: Sequence[bytes], check: int = CHECK_NONE):
+    """Decode independent streams in one launch.  Returns a list of
+    (rc, output, got, used, check) -- the tuple yeast() would give per stream plus the check."""
+    L = lib()
+    n = len(streams)
+    if n == 0:
+        return []
+    bufs = [ctypes.create_string_buffer(s, max(len(s), 1)) for s in streams]
+    src = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in bufs])
+    ln = (ctypes.c_size_t * n)(*[len(s) for s in streams])
+    dest = (ctypes.c_void_p * n)()
+    got = (ctypes.c_size_t * n)()
+    rc = (ctypes.c_int * n)()
+    chk = (ctypes.c_uint64 * n)()
+    e = L.yeast_batch(n, src, ln, dest, got, rc, check, chk)
+    if e:
+        raise _err("yeast_batch")
+    out = []
+    for i in range(n):
+        data = ctypes.string_at(dest[i], got[i]) if dest[i] else b""
+        if dest[i]:
+            _libc.free(dest[i])
+        out.append((rc[i], data, got[i], ln[i], chk[i]))
+    return out
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    return lib().crc32c(crc, data, len(data))
+
+
+def xxh32(data: bytes, seed: int = 0) -> int:
+    return lib().XXH32(data, len(data), seed)
+
+
+def xxh64(data: bytes, seed: int = 0) -> int:
+    return lib().XXH64(data, len(data), seed)
+
+
+def debug_table(which: int) -> bytes:
+    sz = ctypes.c_size_t(0)
+    p = lib().yeast_debug_table(which, ctypes.byref(sz))
+    return ctypes.string_at(p, sz.value) if p else b""

@@ -1,0 +1,14 @@
+#!/bin/sh
+# Build libyeast_mi355x.so (gfx950 only) in-tree.  Usage: brotli_amd/csrc/build.sh
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT="$HERE/.."
+DATA="$OUT/data"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
+cd "$HERE"
+$HIPCC $FLAGS -c yeast_kernels.hip -o yeast_kernels.o ${YEAST_EXTRA_FLAGS}
+$HIPCC $FLAGS -c yeast_host.cpp -o yeast_host.o
+gcc -O2 -fPIC -DYS_DATA_DIR="\"$DATA\"" -c yeast_data.c -o yeast_data.o
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT/libyeast_mi355x.so" yeast_kernels.o yeast_host.o yeast_data.o
+echo "built $OUT/libyeast_mi355x.so"

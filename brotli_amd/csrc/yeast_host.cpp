@@ -1,0 +1,536 @@
+/*
+ * yeast_host.cpp -- host side of libyeast_mi355x.so: the C-ABI of
+ * include/yeast.h and include/yeast_batch.h on top of the HIP kernels in
+ * yeast_kernels.hip.  No decode logic lives here: the host only stages
+ * buffers, sizes output regions, launches, and retries a stream whose output
+ * region or table arena turned out too small.
+ *
+ * Reference counterparts: yeast() yeast.c:1353-1400 (contract yeast.h:7-25);
+ * crc32c() crc32c.c:258; XXH32()/XXH64() xxhash.c:365,505.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+#include "yeast_common.h"
+#include "../../include/yeast.h"
+#include "../../include/yeast_batch.h"
+
+extern "C" {
+extern const unsigned char ys_dictionary[122784];
+extern const unsigned char ys_transforms[2420];
+int ys_upload_constants(const u8 *lut768, const u32 *x2n);
+int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned groups, void *stream);
+int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec, unsigned n, unsigned kind, u64 seed,
+                    void *stream);
+int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed, u64 *out, void *stream);
+int yeast_verbosity = 0;
+}
+
+static_assert(sizeof(ys_record) == 32 && sizeof(yeast_record) == 32, "record layout");
+
+static thread_local char t_err[256] = "";
+static std::mutex g_mu;
+
+static int fail(const char *what, hipError_t e)
+{
+    snprintf(t_err, sizeof(t_err), "libyeast_mi355x: %s: %s", what, hipGetErrorString(e));
+    fprintf(stderr, "%s\n", t_err);
+    return -1;
+}
+#define HIPCK(call)                  \
+    do {                             \
+        hipError_t e_ = (call);      \
+        if (e_ != hipSuccess)        \
+            return fail(#call, e_);  \
+    } while (0)
+
+extern "C" const char *yeast_last_error(void) { return t_err; }
+
+extern "C" int yeast_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+/* ---- static tables ------------------------------------------------------- */
+
+/* The three literal-context tables (reference: lut0/lut1/lut2, yeast.c:700-740),
+   generated from run-length descriptions of RFC 7932 section 7.1. */
+static void make_ctx_luts(u8 *t)
+{
+    u8 *l0 = t, *l1 = t + 256, *l2 = t + 512;
+    static const u8 l0_32[96] = {
+        8,  12, 16, 12, 12, 20, 12, 16, 24, 28, 12, 12, 32, 12, 36, 12, 44, 44, 44, 44, 44, 44, 44, 44,
+        44, 44, 32, 32, 24, 40, 28, 12, 12, 48, 52, 52, 52, 48, 52, 52, 52, 48, 52, 52, 52, 52, 52, 48,
+        52, 52, 52, 52, 52, 48, 52, 52, 52, 52, 52, 24, 12, 28, 12, 12, 12, 56, 60, 60, 60, 56, 60, 60,
+        60, 56, 60, 60, 60, 60, 60, 56, 60, 60, 60, 60, 60, 56, 60, 60, 60, 60, 60, 24, 12, 28, 12, 0};
+    memset(l0, 0, 32);
+    l0[9] = l0[10] = l0[13] = 4;
+    memcpy(l0 + 32, l0_32, 96);
+    for (int c = 128; c < 256; c++)
+        l0[c] = (u8)((c & 1) + (c >= 192 ? 2 : 0));
+    /* lut1: class of the second-last byte */
+    struct Run { int upto; u8 v; };
+    static const Run r1[] = {{33, 0}, {48, 1}, {58, 2}, {65, 1}, {91, 2}, {97, 1}, {123, 3}, {127, 1}, {224, 0}, {256, 2}};
+    static const Run r2[] = {{1, 0}, {16, 1}, {64, 2}, {128, 3}, {192, 4}, {240, 5}, {255, 6}, {256, 7}};
+    int c = 0;
+    for (const Run &r : r1)
+        for (; c < r.upto; c++)
+            l1[c] = r.v;
+    c = 0;
+    for (const Run &r : r2)
+        for (; c < r.upto; c++)
+            l2[c] = r.v;
+}
+
+#define CRC_POLY 0x82f63b78u
+static u32 crc_mul(u32 a, u32 b)
+{
+    u32 p = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & 0x80000000u)
+            p ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1) ? CRC_POLY : 0);
+    }
+    return p;
+}
+
+/* ---- per-device state ------------------------------------------------------ */
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Device {
+    bool ready = false;
+    u8 *d_dict = nullptr, *d_xf = nullptr;
+    int cus = 256;
+    Buf src, dst, soff, doff, rec, ws, ws_big, ctr, scratch;
+};
+
+static Device g_dev[64];
+static u8 g_luts[768];
+static bool g_luts_ready = false;
+
+static int grow(Buf &b, size_t need)
+{
+    if (need <= b.cap && b.p)
+        return 0;
+    if (b.p)
+        (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t cap = need + need / 4 + 4096;
+    HIPCK(hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return 0;
+}
+
+static int device_get(Device **out)
+{
+    int id = 0;
+    HIPCK(hipGetDevice(&id));
+    if (id < 0 || id >= 64) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: device id %d out of range", id);
+        fprintf(stderr, "%s\n", t_err);
+        return -1;
+    }
+    Device &d = g_dev[id];
+    if (!d.ready) {
+        if (!g_luts_ready) {
+            make_ctx_luts(g_luts);
+            g_luts_ready = true;
+        }
+        u32 x2n[68];
+        x2n[0] = 0x40000000u;
+        for (int k = 1; k < 68; k++)
+            x2n[k] = crc_mul(x2n[k - 1], x2n[k - 1]);
+        int e = ys_upload_constants(g_luts, x2n);
+        if (e)
+            return fail("upload constants (is a gfx950 code object present?)", (hipError_t)e);
+        HIPCK(hipMalloc((void **)&d.d_dict, sizeof(ys_dictionary)));
+        HIPCK(hipMalloc((void **)&d.d_xf, 4096));
+        HIPCK(hipMemcpy(d.d_dict, ys_dictionary, sizeof(ys_dictionary), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(d.d_xf, ys_transforms, sizeof(ys_transforms), hipMemcpyHostToDevice));
+        hipDeviceProp_t prop;
+        HIPCK(hipGetDeviceProperties(&prop, id));
+        d.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        d.ready = true;
+    }
+    *out = &d;
+    return 0;
+}
+
+extern "C" const unsigned char *yeast_debug_table(int which, size_t *size)
+{
+    if (!g_luts_ready) {
+        make_ctx_luts(g_luts);
+        g_luts_ready = true;
+    }
+    if (which >= 0 && which < 3) {
+        *size = 256;
+        return g_luts + 256 * which;
+    }
+    if (which == 3) {
+        *size = sizeof(ys_dictionary);
+        return ys_dictionary;
+    }
+    if (which == 4) {
+        *size = sizeof(ys_transforms);
+        return ys_transforms;
+    }
+    *size = 0;
+    return nullptr;
+}
+
+/* ---- launch ------------------------------------------------------------------ */
+
+static int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+/* Enqueue decode (+ retry pass for streams whose tables did not fit the
+   default arena, + check values) for n streams.  Everything is device
+   resident; nothing here synchronises. */
+static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64 *doff, ys_record *rec, size_t n,
+                   unsigned check_kind, int lanes, int cmp, hipStream_t st)
+{
+    if (n == 0)
+        return 0;
+    if (n > 0x7fffffffu) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: batch too large");
+        return -1;
+    }
+    if (lanes == 0)
+        lanes = env_int("YEAST_LANES", 8);
+    if (cmp)
+        lanes = 64;
+    if (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: lanes_per_stream must be a power of two <= 64");
+        return -1;
+    }
+    unsigned per_block = 256u / (unsigned)lanes;
+    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", 4);
+    size_t want_blocks = (n + per_block - 1) / per_block;
+    size_t max_blocks = (size_t)d.cus * blocks_per_cu;
+    unsigned blocks = (unsigned)(want_blocks < max_blocks ? want_blocks : max_blocks);
+    unsigned groups = blocks * per_block;
+    u64 stride = (u64)env_int("YEAST_WS_KB", 48) * 1024;
+    if (stride < YS_WS_ARENA + 8192)
+        stride = YS_WS_ARENA + 8192;
+    if (grow(d.ws, (size_t)groups * stride))
+        return -1;
+    /* counters: [0] main queue head, [1] retry queue head, [2] retry count; then the retry list */
+    if (grow(d.ctr, 16 + n * sizeof(u32)))
+        return -1;
+    HIPCK(hipMemsetAsync(d.ctr.p, 0, 16, st));
+
+    ys_params p;
+    memset(&p, 0, sizeof(p));
+    p.src = src;
+    p.src_off = soff;
+    p.dst = dst;
+    p.dst_off = doff;
+    p.rec = rec;
+    p.ws = (u8 *)d.ws.p;
+    p.ws_stride = stride;
+    p.counter = (u32 *)d.ctr.p;
+    p.retry_count = (u32 *)d.ctr.p + 2;
+    p.retry_list = (u32 *)d.ctr.p + 4;
+    p.retry = 0;
+    p.n = (u32)n;
+    p.dict = d.d_dict;
+    p.xforms = d.d_xf;
+    int e = ys_launch_decode(&p, lanes, cmp, groups, st);
+    if (e)
+        return fail("decode launch", (hipError_t)e);
+
+    /* retry pass: whole wavefronts, worst-case arena; exits at once when the list is empty */
+    const unsigned big_groups = 64;
+    if (grow(d.ws_big, (size_t)big_groups * YS_WS_MAX))
+        return -1;
+    p.ws = (u8 *)d.ws_big.p;
+    p.ws_stride = YS_WS_MAX;
+    p.counter = (u32 *)d.ctr.p + 1;
+    p.retry = 1;
+    e = ys_launch_decode(&p, 64, cmp, big_groups, st);
+    if (e)
+        return fail("retry launch", (hipError_t)e);
+
+    if (check_kind) {
+        e = ys_launch_check(dst, doff, rec, (unsigned)n, check_kind, 0, st);
+        if (e)
+            return fail("check launch", (hipError_t)e);
+    }
+    return 0;
+}
+
+extern "C" int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, void *d_dst,
+                                  const uint64_t *d_dst_off, yeast_record *d_rec, size_t n, unsigned check_kind,
+                                  int lanes_per_stream, void *hip_stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Device *d;
+    if (device_get(&d))
+        return -1;
+    if (check_kind > 3) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: unknown check kind %u", check_kind);
+        return -1;
+    }
+    return enqueue(*d, (const u8 *)d_src, d_src_off, (u8 *)d_dst, d_dst_off, (ys_record *)d_rec, n, check_kind,
+                   lanes_per_stream, 0, (hipStream_t)hip_stream);
+}
+
+extern "C" int yeast_check_device(const void *d_dst, const uint64_t *d_dst_off, yeast_record *d_rec, size_t n,
+                                  unsigned check_kind, void *hip_stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Device *d;
+    if (device_get(&d))
+        return -1;
+    if (check_kind < 1 || check_kind > 3) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: unknown check kind %u", check_kind);
+        return -1;
+    }
+    int e = ys_launch_check((const u8 *)d_dst, d_dst_off, (ys_record *)d_rec, (unsigned)n, check_kind, 0,
+                            hip_stream);
+    if (e)
+        return fail("check launch", (hipError_t)e);
+    return 0;
+}
+
+/* ---- host-pointer paths ---------------------------------------------------- */
+
+/* Read WBITS and the first meta-block header on the host, only to size the
+   output region (yeast.c:1372-1378, 990-1038).  Returns a guess of the output
+   size; never an error: the kernels do the real parse. */
+static u64 first_mlen_guess(const u8 *s, size_t len)
+{
+    u64 pos = 0, nbits = (u64)len * 8;
+    auto bits = [&](unsigned n, u32 &v) -> bool {
+        if (pos + n > nbits)
+            return false;
+        v = 0;
+        for (unsigned i = 0; i < n; i++, pos++)
+            v |= (u32)((s[pos >> 3] >> (pos & 7)) & 1) << i;
+        return true;
+    };
+    u32 v, n;
+    if (!bits(1, v))
+        return 0;
+    if (v) {
+        if (!bits(3, v))
+            return 0;
+        if (!v) {
+            if (!bits(3, v))
+                return 0;
+        }
+    }
+    u32 last;
+    if (!bits(1, last))
+        return 0;
+    if (last) {
+        if (!bits(1, v) || v)
+            return 0;
+    }
+    if (!bits(2, n) || n == 3)
+        return 0;
+    if (!bits(16, v))
+        return 0;
+    u64 mlen = 1 + (u64)v;
+    if (n) {
+        if (!bits(n << 2, v))
+            return 0;
+        mlen += (u64)v << 16;
+    }
+    return mlen;
+}
+
+static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+/* Decode n host streams; fills rec[] and, for cmp == 0, out[i] (malloc'd).
+   expected/have: compare mode inputs (cmp != 0, n == 1 in practice). */
+static int run_host_batch(size_t n, void const *const *src, const size_t *len, std::vector<ys_record> &rec,
+                          void **out, unsigned check_kind, int cmp, const void *expected, size_t have)
+{
+    Device *dp;
+    if (device_get(&dp))
+        return -1;
+    Device &d = *dp;
+    hipStream_t st = nullptr;
+    rec.assign(n, ys_record{});
+    std::vector<u64> soff(n + 1), doff(n + 1);
+    std::vector<size_t> todo(n);
+    std::vector<u64> cap(n);
+    for (size_t i = 0; i < n; i++) {
+        todo[i] = i;
+        if (cmp)
+            cap[i] = have;
+        else {
+            u64 g = first_mlen_guess((const u8 *)src[i], len[i]);
+            u64 c = g ? g : 65536;
+            if (c < 4096)
+                c = 4096;
+            cap[i] = c;
+        }
+        if (out)
+            out[i] = nullptr;
+    }
+    int lanes = n >= 2048 ? 0 : 64;
+
+    while (!todo.empty()) {
+        size_t m = todo.size();
+        u64 stot = 0, dtot = 0;
+        for (size_t k = 0; k < m; k++) {
+            soff[k] = stot;
+            stot += len[todo[k]];
+            doff[k] = dtot;
+            dtot += cmp ? cap[todo[k]] : round_up(cap[todo[k]], 16);
+        }
+        soff[m] = stot;
+        doff[m] = dtot;
+        if (cmp)
+            doff[m] = doff[0] + have;
+        if (grow(d.src, stot + YS_SRC_PAD + 64) || grow(d.dst, dtot + 64) || grow(d.soff, (m + 1) * 8) ||
+            grow(d.doff, (m + 1) * 8) || grow(d.rec, m * sizeof(ys_record)))
+            return -1;
+        /* stage the inputs through one pinned-size host vector */
+        std::vector<u8> pack(stot + YS_SRC_PAD, 0);
+        for (size_t k = 0; k < m; k++)
+            if (len[todo[k]])
+                memcpy(pack.data() + soff[k], src[todo[k]], len[todo[k]]);
+        HIPCK(hipMemcpyAsync(d.src.p, pack.data(), pack.size(), hipMemcpyHostToDevice, st));
+        HIPCK(hipMemcpyAsync(d.soff.p, soff.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCK(hipMemcpyAsync(d.doff.p, doff.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
+        if (cmp && have)
+            HIPCK(hipMemcpyAsync(d.dst.p, expected, have, hipMemcpyHostToDevice, st));
+        if (enqueue(d, (const u8 *)d.src.p, (const u64 *)d.soff.p, (u8 *)d.dst.p, (const u64 *)d.doff.p,
+                    (ys_record *)d.rec.p, m, check_kind, lanes, cmp, st))
+            return -1;
+        std::vector<ys_record> r(m);
+        HIPCK(hipMemcpyAsync(r.data(), d.rec.p, m * sizeof(ys_record), hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+
+        std::vector<size_t> again;
+        for (size_t k = 0; k < m; k++) {
+            size_t i = todo[k];
+            if (r[k].rc == YS_CAPACITY) {
+                u64 need = r[k].check;
+                u64 c2 = cap[i] * 2;
+                cap[i] = need > c2 ? need : c2;
+                again.push_back(i);
+                continue;
+            }
+            if (r[k].rc == YS_WORKSPACE) { /* cannot happen after the worst-case retry pass */
+                snprintf(t_err, sizeof(t_err), "libyeast_mi355x: internal: table arena exhausted");
+                fprintf(stderr, "%s\n", t_err);
+                return -1;
+            }
+            rec[i] = r[k];
+            if (!cmp && out && r[k].got) {
+                out[i] = malloc(r[k].got);
+                if (!out[i])
+                    return 1;
+                HIPCK(hipMemcpyAsync(out[i], (u8 *)d.dst.p + doff[k], r[k].got, hipMemcpyDeviceToHost, st));
+            }
+        }
+        HIPCK(hipStreamSynchronize(st));
+        todo.swap(again);
+    }
+    return 0;
+}
+
+extern "C" int yeast(void **dest, size_t *got, void const *source, size_t *len, int cmp)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<ys_record> rec;
+    void *out = nullptr;
+    const void *srcs[1] = {source};
+    size_t lens[1] = {*len};
+    const void *expected = cmp && *got ? *dest : nullptr;
+    size_t have = cmp ? *got : 0;
+    int e = run_host_batch(1, srcs, lens, rec, cmp ? nullptr : &out, 0, cmp ? 1 : 0, expected, have);
+    if (e) {
+        free(out);
+        if (!cmp)
+            *dest = nullptr;
+        *got = 0;
+        *len = 0;
+        return e;
+    }
+    *len = (size_t)rec[0].used;
+    *got = (size_t)rec[0].got;
+    if (!cmp)
+        *dest = out;
+    if (yeast_verbosity > 0)
+        fprintf(stderr, "yeast: window bits %u, %u meta-block%s, %zu bytes out, %zu bytes used%s\n",
+                rec[0].flags & 255, rec[0].flags >> 8, (rec[0].flags >> 8) == 1 ? "" : "s", *got, *len,
+                rec[0].rc ? " -- error: aborting" : "");
+    return rec[0].rc;
+}
+
+extern "C" int yeast_batch(size_t n, void const *const *src, size_t *len, void **dest, size_t *got, int *rc,
+                           unsigned check_kind, uint64_t *check)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (check_kind > 3) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: unknown check kind %u", check_kind);
+        return -1;
+    }
+    std::vector<ys_record> rec;
+    int e = run_host_batch(n, src, len, rec, dest, check_kind, 0, nullptr, 0);
+    if (e)
+        return e;
+    for (size_t i = 0; i < n; i++) {
+        len[i] = (size_t)rec[i].used;
+        got[i] = (size_t)rec[i].got;
+        rc[i] = rec[i].rc;
+        if (check && check_kind)
+            check[i] = rec[i].check;
+    }
+    return 0;
+}
+
+/* ---- check functions over host buffers --------------------------------------- */
+
+static u64 host_check(const void *buf, size_t len, unsigned kind, u64 seed)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Device *d;
+    u64 v = 0;
+    bool ok = device_get(&d) == 0 && grow(d->scratch, len + 64) == 0 && grow(d->rec, 64) == 0;
+    if (ok && len)
+        ok = hipMemcpy(d->scratch.p, buf, len, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok)
+        ok = ys_launch_check_buf((const u8 *)d->scratch.p, len, kind, seed, (u64 *)d->rec.p, nullptr) == 0;
+    if (ok)
+        ok = hipMemcpy(&v, d->rec.p, 8, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "libyeast_mi355x: check value could not be computed on the GPU (%s)\n", t_err);
+        abort();
+    }
+    return v;
+}
+
+extern "C" uint32_t crc32c(uint32_t crc, void const *buf, size_t len)
+{
+    return (uint32_t)host_check(buf, len, YEAST_CHECK_CRC32C, crc);
+}
+extern "C" unsigned int XXH32(const void *input, size_t len, unsigned int seed)
+{
+    return (unsigned int)host_check(input, len, YEAST_CHECK_XXH32, seed);
+}
+extern "C" unsigned long long XXH64(const void *input, size_t len, unsigned long long seed)
+{
+    return host_check(input, len, YEAST_CHECK_XXH64, seed);
+}

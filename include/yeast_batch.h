@@ -1,0 +1,99 @@
+/*
+ * include/yeast_batch.h -- additive batch / device-resident entry points of
+ * libyeast_mi355x.so, and the check-value functions.
+ *
+ * The reference decodes one stream per call (yeast.h:25).  Its callers that
+ * handle many streams loop over yeast() (juxt.c:77-93 over files, broad.c:142-353
+ * over the segments of a .br file) and then compute a check over each output
+ * (brand.c:245-248, broad.c:278-281).  These entry points are what an FFI
+ * binding for that loop would call instead: the same per-stream results
+ * (rc, *got, *len, output bytes, check value) for n independent streams in
+ * one launch.  Plain pointers and sizes only.
+ */
+#ifndef YEAST_BATCH_H
+#define YEAST_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* check kinds (the three non-cryptographic checks of br.h / brand.c:245-248) */
+#define YEAST_CHECK_NONE 0
+#define YEAST_CHECK_CRC32C 1
+#define YEAST_CHECK_XXH32 2
+#define YEAST_CHECK_XXH64 3
+
+/* Per-stream result record (32 bytes).  rc uses yeast()'s codes 0..4; the
+   device-resident call can also report 5 = the stream's output region was too
+   small (check then holds the size needed so far). */
+typedef struct {
+    int32_t rc;
+    uint32_t flags; /* bits 0..7 window bits, bits 8..31 meta-blocks decoded */
+    uint64_t got;   /* == *got of yeast() */
+    uint64_t used;  /* == *len of yeast() on return */
+    uint64_t check; /* check value of the got output bytes (kind chosen by the caller) */
+} yeast_record;
+
+/* Extra readable bytes required after the last stream of a device-resident
+   source buffer (the bit reader prefetches whole words). */
+#define YEAST_SRC_PAD 32
+
+/*
+ * Host-pointer batch: yeast(cmp=0) for each of n streams (replaces a loop
+ * over yeast.h:25 such as juxt.c:77-93).  len[i] is in: size / out: bytes
+ * consumed; dest[i] receives a malloc() buffer (NULL when got[i] is 0);
+ * rc[i] the per-stream return code.  If check_kind != 0, check[i] receives
+ * the check value of stream i's output (crc32c(0,..), XXH32(..,0), XXH64(..,0)).
+ * Returns 0, or -1 when the GPU path is unavailable (message on stderr) and 1
+ * when host memory ran out.
+ */
+int yeast_batch(size_t n, void const *const *src, size_t *len, void **dest, size_t *got, int *rc,
+                unsigned check_kind, uint64_t *check);
+
+/*
+ * Device-resident batch.  All pointers are device pointers on the current
+ * HIP device; the call only enqueues work on hip_stream (a hipStream_t, or
+ * NULL for the default stream) and returns.
+ *   d_src      packed compressed streams, YEAST_SRC_PAD readable bytes after the end
+ *   d_src_off  n+1 offsets: stream i is d_src[d_src_off[i] .. d_src_off[i+1])
+ *   d_dst      output arena; stream i may use d_dst[d_dst_off[i] .. d_dst_off[i+1])
+ *   d_rec      n records, written by the kernels
+ *   lanes_per_stream  0 = library default, else 1,2,4,8,16,32 or 64 lanes of a
+ *              wavefront cooperate on one stream
+ * Returns 0 or a negative error (see yeast_last_error()).
+ */
+int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, void *d_dst, const uint64_t *d_dst_off,
+                       yeast_record *d_rec, size_t n, unsigned check_kind, int lanes_per_stream,
+                       void *hip_stream);
+
+/* Check values only, over outputs already in device memory: fills
+   d_rec[i].check from d_dst[d_dst_off[i] .. +d_rec[i].got). */
+int yeast_check_device(const void *d_dst, const uint64_t *d_dst_off, yeast_record *d_rec, size_t n,
+                       unsigned check_kind, void *hip_stream);
+
+/*
+ * The reference's check functions over host buffers, computed on the GPU:
+ *   crc32c()  replaces crc32c.h:13 / crc32c.c:258 (chainable through crc)
+ *   XXH32()   replaces xxhash.h XXH32  (xxhash.c:365)
+ *   XXH64()   replaces xxhash.h XXH64  (xxhash.c:505)
+ * On a GPU failure they write a message to stderr and abort(): there is no
+ * in-band error value in these signatures.
+ */
+uint32_t crc32c(uint32_t crc, void const *buf, size_t len);
+unsigned int XXH32(const void *input, size_t len, unsigned int seed);
+unsigned long long XXH64(const void *input, size_t len, unsigned long long seed);
+
+/* Diagnostics. */
+const char *yeast_last_error(void);   /* thread-local text of the last failure, "" if none */
+int yeast_device_count(void);         /* HIP devices visible, <= 0 if none */
+const unsigned char *yeast_debug_table(int which, size_t *size);
+/* which: 0,1,2 = the three literal-context tables (yeast.c:700-740), 3 = dictionary,
+   4 = transform records; for table known-answer tests (check.c:94-99) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""Shared test helpers: the oracle (test-only checker) and the golden fixtures."""
+import ctypes
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [ctypes.c_void_p]
+_oracle = None
+_ref = None
+
+
+def oracle():
+    """oracle/liboracle.so -- CPU restatement, test infrastructure only."""
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        L = ctypes.CDLL(path)
+        L.oracle_yeast.restype = ctypes.c_int
+        L.oracle_crc32c.restype = ctypes.c_uint32
+        L.oracle_crc32c.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+        L.oracle_xxh32.restype = ctypes.c_uint32
+        L.oracle_xxh32.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+        L.oracle_xxh64.restype = ctypes.c_uint64
+        L.oracle_xxh64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
+        L.oracle_dict_word.restype = ctypes.c_int
+        L.oracle_dict_word.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
+        L.oracle_context_lut.restype = ctypes.c_void_p
+        _oracle = L
+    return _oracle
+
+
+def reference():
+    """oracle/_ref/libyeast_ref.so -- the real reference, present only where it was built."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libyeast_ref.so")
+        if not os.path.exists(path):
+            return None
+        L = ctypes.CDLL(path)
+        L.yeast.restype = ctypes.c_int
+        L.crc32c.restype = ctypes.c_uint32
+        L.crc32c.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+        L.XXH32.restype = ctypes.c_uint32
+        L.XXH32.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+        L.XXH64.restype = ctypes.c_uint64
+        L.XXH64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
+        _ref = L
+    return _ref
+
+
+def run_yeast(fn, src: bytes, expected=None):
+    """Call a yeast()-shaped C function.  Decode mode -> (rc, got, used, out);
+    compare mode -> (rc, got, used, None)."""
+    buf = ctypes.create_string_buffer(src, max(len(src), 1))
+    ln = ctypes.c_size_t(len(src))
+    if expected is None:
+        dest = ctypes.c_void_p(None)
+        got = ctypes.c_size_t(0)
+        rc = fn(ctypes.byref(dest), ctypes.byref(got), buf, ctypes.byref(ln), 0)
+        out = ctypes.string_at(dest.value, got.value) if dest.value else b""
+        if dest.value:
+            _libc.free(dest)
+        return rc, got.value, ln.value, out
+    keep = ctypes.create_string_buffer(expected, max(len(expected), 1))
+    dest = ctypes.c_void_p(ctypes.addressof(keep))
+    got = ctypes.c_size_t(len(expected))
+    rc = fn(ctypes.byref(dest), ctypes.byref(got), buf, ctypes.byref(ln), 1)
+    return rc, got.value, ln.value, None
+
+
+def oracle_yeast(src: bytes, expected=None):
+    return run_yeast(oracle().oracle_yeast, src, expected)
+
+
+def load_json(name):
+    return json.load(open(os.path.join(GOLD, name)))
+
+
+def testdata_pairs():
+    d = os.path.join(GOLD, "testdata")
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".compressed"):
+            yield f, open(os.path.join(d, f), "rb").read(), open(os.path.join(d, f[:-11]), "rb").read()
+
+
+def packed_streams(name):
+    meta = load_json(name + ".json")
+    blob = open(os.path.join(GOLD, name + ".bin"), "rb").read()
+    return meta, [blob[m["off"]:m["off"] + m["len"]] for m in meta["streams"]]
