@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: decompressed GB/s (whole node), batched 64 KiB brotli streams.
+
+One step = one pass of the hot path over one batch: decode every stream of the batch
+(yeast_batch_device), compute the XXH64 check of every output (fused into the same call), and --
+for N > 1 -- all-gather the 32-byte result records over RCCL.  Inputs are resident in HBM before
+the timed region starts.
+
+Workload (config.workload = "cfg2"): 65,536 independent streams per GPU, each decoding to 65,536
+bytes (English text, brotli quality 11, lgwin 22), tiled from the 256 distinct committed streams of
+tests/golden/cfg2_streams.bin in a fixed pseudo-random order.  Scaling is weak: every rank decodes
+its own 65,536-stream shard; value = bytes decoded by all ranks / max-over-ranks time.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through
+python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def load_distinct():
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg2_streams.json")))
+    blob = open(os.path.join(ROOT, "tests", "golden", "cfg2_streams.bin"), "rb").read()
+    streams = [blob[m["off"]:m["off"] + m["len"]] for m in meta["streams"]]
+    return meta["streams"], streams
+
+
+def build_order(n, ndistinct, seed):
+    """stream i of the batch = distinct[order[i]]: every distinct stream equally often, order permuted."""
+    rng = np.random.RandomState(seed)
+    reps = (n + ndistinct - 1) // ndistinct
+    order = np.tile(np.arange(ndistinct), reps)[:n]
+    rng.shuffle(order)
+    return order
+
+
+def cpu_baseline(streams, order, cores, sample):
+    """Time the reference decoder (oracle/_ref, built from /root/reference in the build container)
+    -- or, if absent, this repo's CPU restatement -- on a bounded sample of the same batch."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    import helpers as H
+    ref = H.reference()
+    kind = "reference" if ref is not None else "port"
+    fn = ref.yeast if ref is not None else H.oracle().oracle_yeast
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    bufs = [ctypes.create_string_buffer(s, len(s)) for s in streams]
+    idx = [int(order[i % len(order)]) for i in range(sample)]
+
+    def work(lo, hi):
+        tot = 0
+        for j in idx[lo:hi]:
+            dest = ctypes.c_void_p(None)
+            got = ctypes.c_size_t(0)
+            ln = ctypes.c_size_t(len(streams[j]))
+            rc = fn(ctypes.byref(dest), ctypes.byref(got), bufs[j], ctypes.byref(ln), 0)
+            assert rc == 0
+            tot += got.value
+            libc.free(dest)
+        return tot
+    per = (sample + cores - 1) // cores
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        futs = [ex.submit(work, k * per, min(sample, (k + 1) * per)) for k in range(cores)]
+        total = sum(f.result() for f in futs)
+    dt = time.perf_counter() - t0
+    return {"value": total / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": kind,
+            "sample": "%d streams of the cfg2 batch (%d bytes out), one yeast() call per stream over %d threads"
+                      % (sample, total, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (default: the cfg2 batch)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per stream (0 = library default)")
+    ap.add_argument("--check", type=int, default=3, help="0 none, 1 crc32c, 2 xxh32, 3 xxh64")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="streams for the host baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import brotli_amd as ba
+    from brotli_amd.device import DeviceBatch, RECORD_DTYPE
+    from brotli_amd.sharding import all_gather_records
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    meta, distinct = load_distinct()
+    n = args.streams
+    order = build_order(n, len(distinct), 0x5EED + rank)
+    streams = [distinct[j] for j in order]
+    batch = DeviceBatch(streams, [65536] * n, device=dev)
+    want_got = np.array([meta[j]["got"] for j in order], dtype=np.uint64)
+    want_used = np.array([meta[j]["len"] for j in order], dtype=np.uint64)
+    want_chk = np.array([int(meta[j][{1: "crc32c", 2: "xxh32", 3: "xxh64"}.get(args.check, "xxh64")], 16)
+                         for j in order], dtype=np.uint64)
+    del streams
+
+    def step():
+        batch.decode(check=args.check, lanes=args.lanes)
+        if dist is not None:
+            return all_gather_records(batch.rec, dist)
+        return batch.rec
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # verify once, outside the timed region: every stream decoded, sizes and checks as the fixtures say
+    r = batch.records()
+    ok = (r["rc"] == 0).all() and (r["got"] == want_got).all() and (r["used"] == want_used).all()
+    if args.check:
+        ok = ok and (r["check"] == want_chk).all()
+    if not ok:
+        bad = int(np.argmax((r["rc"] != 0) | (r["got"] != want_got) | (r["check"] != want_chk)))
+        raise SystemExit("bench: decode results do not match the fixtures (first bad stream %d: %s)" % (bad, r[bad]))
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # kernel-level timing for the roofline: HIP events on the stream the kernels are launched on,
+    # decode only (no check, no gather), K launches
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        batch.decode(check=0, lanes=args.lanes)
+        b.record()
+    torch.cuda.synchronize()
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    evc = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if args.check:
+        for a, b in evc:
+            a.record()
+            batch.check(args.check)
+            b.record()
+        torch.cuda.synchronize()
+        c_ms = float(np.mean([a.elapsed_time(b) for a, b in evc]))
+    else:
+        c_ms = 0.0
+
+    out_bytes = float(want_got.sum())
+    in_bytes = float(want_used.sum())
+    algo = out_bytes + in_bytes  # B = used_in + got_out per stream
+    ms_per_step = dt / args.steps * 1e3
+    value = out_bytes * world / (dt / args.steps) / 1e9
+    achieved = algo / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tf):
+        try:
+            t = json.load(open(tf))
+            if t.get("streams") == n:
+                traffic = t.get("bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "decompressed GB/s (whole node), batched 64 KiB brotli streams",
+        "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "cfg2: %d streams/GPU x 65,536 B out, q11 lgwin22 English text, %d distinct "
+                               "streams tiled in seeded order; decode + %s check%s"
+                               % (n, len(distinct), {0: "no", 1: "CRC-32C", 2: "XXH32", 3: "XXH64"}[args.check],
+                                  " + RCCL all-gather of records" if world > 1 else ""),
+                   "streams_per_gpu": n, "out_bytes_per_gpu": out_bytes, "in_bytes_per_gpu": in_bytes,
+                   "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "8")),
+                   "parallelism": "%d independent shards" % world},
+        "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": algo, "kernel_ms": k_ms, "check_kernel_ms": c_ms},
+    }
+    if rank == 0 and world == 1 and args.cpu_sample:
+        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        line["cpu_baseline"] = cpu_baseline(distinct, order, cores, min(args.cpu_sample, max(n, 256)))
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

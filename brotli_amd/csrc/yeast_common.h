@@ -57,15 +57,16 @@ typedef struct {
 #define YS_SRC_PAD 32
 
 /* workspace slot layout (bytes from the slot base) */
-#define YS_NDIR 774         /* 6 block-switch codes + 256 literal + 256 iac + 256 distance */
-#define YS_WS_DIR 0         /* u32[774]: table offsets (u16 units from YS_WS_ARENA) */
-#define YS_WS_MODE 3104     /* u8[256] context modes */
-#define YS_WS_DMAP 3360     /* u8[1024] distance context map */
-#define YS_WS_SORT 4384     /* u16[704] symbols in canonical order */
-#define YS_WS_MTF 5792      /* u8[256] move-to-front list */
-#define YS_WS_ARENA 6144    /* literal context map, then code tables */
-#define YS_WS_MIN (YS_WS_ARENA + 16384 + 64 * 1024)
-/* worst case: 16 KiB literal map + 774 tables of at most 1,100 u16 entries */
-#define YS_WS_MAX (YS_WS_ARENA + 16384 + 774 * 2208)
+#define YS_WS_ITAB 0        /* u32[256]  byte offset (from the slot base) of each insert-and-copy table */
+#define YS_WS_DTAB 1024     /* u32[1024] byte offset of the distance table per (block type, context) */
+#define YS_WS_MODE 5120     /* u8[256]   literal context modes */
+#define YS_WS_DMAP 5376     /* u8[1024]  distance context map */
+#define YS_WS_SORT 6400     /* u16[704]  symbols in canonical order (table build scratch) */
+#define YS_WS_MTF 7808      /* u8[256]   move-to-front list */
+#define YS_WS_LDIR 8064     /* u32[256]  byte offset of each literal table (header only) */
+#define YS_WS_DDIR 9088     /* u32[256]  byte offset of each distance table (header only) */
+#define YS_WS_ARENA 10240   /* block-switch tables, literal context map, literal table map, code tables */
+/* worst case: 16 KiB literal map + 64 KiB literal table map + 774 tables of at most 1,104 u16 entries */
+#define YS_WS_MAX (YS_WS_ARENA + 16384 + 65536 + 774 * 2208 + 4096)
 
 #endif

@@ -1,0 +1,1210 @@
+/*
+ * yeast_decode.hip -- MI355X (gfx950) Brotli decode kernel.
+ *
+ * What this replaces in the reference (paths relative to /root/reference):
+ *   yeast.c:163-179   bits()            -> Rd / take() (64-bit window, prefetched dword refills)
+ *   yeast.c:204-219   decode()          -> dec_sym() (two-level LUT, 8-bit root)
+ *   yeast.c:246-348   construct/simple  -> build_table()
+ *   yeast.c:361-542   prefix()          -> read_code()
+ *   yeast.c:550-647   block_length/block_types/context_map
+ *   yeast.c:652-789   insert/copy lengths, context ids, distance()
+ *   yeast.c:795-949   dict_word() + xforms.h + dict.h -> emit_dict()
+ *   yeast.c:971-1308  metablock()       -> metablock()
+ *   yeast.c:1353-1400 yeast()           -> decode_stream()
+ *
+ * Execution model: a *group* of G lanes (G = 64 ... 1, a power of two)
+ * decodes one stream.  Everything that is a function of the bit stream alone
+ * is computed redundantly by every lane of the group (no cross-lane traffic,
+ * no branches on the lane id); the lanes differ only when bytes are moved:
+ * LZ77 window copies, dictionary words and stored blocks are spread over the
+ * G lanes.  Groups pull streams from an atomic work queue, so a launch is a
+ * fixed-size grid of resident groups.
+ *
+ * Errors are sticky: a failed read marks the reader (rc set, no further bits
+ * are handed out, the position freezes) and decoding winds down at the next
+ * loop head.  That keeps the hot loops free of per-read exit paths.
+ */
+#include <hip/hip_runtime.h>
+#include "yeast_common.h"
+
+#define DEV __device__ __forceinline__
+#define NOINL __device__ __noinline__
+
+__constant__ u8 c_ctx_lut[768];  /* lut0 | lut1 | lut2 of yeast.c:700-740, filled by the host */
+__constant__ u32 c_len_tab[48];  /* insert (0..23) and copy (24..47) length codes: base | extra << 16 */
+
+/* LDS image shared by the groups of a block */
+struct Shared {
+    u8 lut[768];
+    u32 len_tab[48];
+};
+
+/* ------------------------------------------------------------- bit reader */
+
+struct Rd {
+    const u32 *p; /* 4-byte aligned base at or before the current seek point */
+    u32 idx;      /* dword index of the next prefetch */
+    u32 nxt;      /* prefetched dword */
+    u64 w;        /* window, next bit at bit 0 */
+    u32 have;     /* bits in w (may extend past the end of the stream) */
+    u64 pos;      /* bits consumed since the start of the stream */
+    u64 nbits;    /* 8 * stream length; forced to 0 once rc is set */
+    u32 rc;       /* sticky status */
+    u32 dry;      /* the reader ran out of input: the reference had pulled every byte */
+};
+
+DEV void rd_fail(Rd &r, u32 code)
+{
+    if (!r.rc)
+        r.rc = code;
+    r.nbits = 0;
+}
+
+DEV void rd_seek(Rd &r, const u8 *src, u64 bitpos)
+{
+    const u8 *at = src + (bitpos >> 3);
+    u32 mis = (u32)((uintptr_t)at & 3);
+    r.p = (const u32 *)(at - mis);
+    u32 sh = mis * 8 + (u32)(bitpos & 7);
+    u64 lo = r.p[0], hi = r.p[1];
+    r.w = (lo | (hi << 32)) >> sh;
+    r.have = 64 - sh;
+    r.nxt = r.p[2];
+    r.idx = 3;
+    r.pos = bitpos;
+}
+
+DEV void rd_refill(Rd &r)
+{
+    if (r.have <= 32) {
+        r.w |= (u64)r.nxt << r.have;
+        r.have += 32;
+        r.nxt = r.p[r.idx++];
+    }
+}
+
+/* bits(): yeast.c:163-179.  n <= 25.  On exhaustion the reference has pulled
+   every input byte (yeast.c:169-175): dry is set and reported as *len. */
+DEV u32 take(Rd &r, u32 n)
+{
+    rd_refill(r);
+    if (r.pos + n > r.nbits) {
+        if (!r.rc) {
+            r.rc = YS_EOF;
+            r.dry = 1;
+        }
+        r.nbits = 0;
+        n = 0;
+    }
+    u32 v = (u32)r.w & ((1u << n) - 1);
+    r.w >>= n;
+    r.have -= n;
+    r.pos += n;
+    return v;
+}
+
+/* "s->left && s->bits": the rest of the current byte is not zero */
+DEV bool tail_nonzero(const Rd &r)
+{
+    u32 k = (u32)(r.pos & 7);
+    return k && ((u32)r.w & ((1u << (8 - k)) - 1));
+}
+
+/* -------------------------------------------------------------- LUT decode
+ * Table entry (u16): bits 0..3 = code length, bits 4..15 = symbol.  In the
+ * 256-entry root a length above 8 marks a link: (length - 8) index bits,
+ * value = offset of the sub-table from the root, in entries.
+ */
+#define ROOT 8
+#define YS_TAB_ENTRIES 1104
+
+DEV u32 dec_sym(Rd &r, const u16 *t)
+{
+    rd_refill(r);
+    u32 peek = (u32)r.w;
+    u32 e = t[peek & 255];
+    u32 l = e & 15;
+    if (l > ROOT) {
+        e = t[(e >> 4) + ((peek >> ROOT) & ((1u << (l - ROOT)) - 1))];
+        l = e & 15;
+    }
+    if (r.pos + l > r.nbits) {
+        if (!r.rc) {
+            r.rc = YS_EOF;
+            r.dry = 1;
+        }
+        r.nbits = 0;
+        l = 0;
+    }
+    r.w >>= l;
+    r.have -= l;
+    r.pos += l;
+    return e >> 4;
+}
+
+/* packed 16 x 16-bit counters in four 64-bit registers (no indexed arrays) */
+struct Cnt16 {
+    u64 q0, q1, q2, q3;
+};
+DEV void cnt_clear(Cnt16 &k) { k.q0 = k.q1 = k.q2 = k.q3 = 0; }
+DEV void cnt_add(Cnt16 &k, u32 i, u32 v)
+{
+    u64 inc = (u64)v << ((i & 3) * 16);
+    u32 q = i >> 2;
+    k.q0 += q == 0 ? inc : 0;
+    k.q1 += q == 1 ? inc : 0;
+    k.q2 += q == 2 ? inc : 0;
+    k.q3 += q == 3 ? inc : 0;
+}
+DEV void cnt_dec(Cnt16 &k, u32 i)
+{
+    u64 inc = (u64)1 << ((i & 3) * 16);
+    u32 q = i >> 2;
+    k.q0 -= q == 0 ? inc : 0;
+    k.q1 -= q == 1 ? inc : 0;
+    k.q2 -= q == 2 ? inc : 0;
+    k.q3 -= q == 3 ? inc : 0;
+}
+DEV u32 cnt_get(const Cnt16 &k, u32 i)
+{
+    u32 q = i >> 2;
+    u64 x = q == 0 ? k.q0 : q == 1 ? k.q1 : q == 2 ? k.q2 : k.q3;
+    return (u32)(x >> ((i & 3) * 16)) & 0xffff;
+}
+
+/* Header-phase state handed to and from the out-of-line header routines. */
+struct Hdr {
+    Rd r;
+    u8 *ws;
+    u32 arena_used, arena_size; /* bytes, relative to ws + YS_WS_ARENA */
+    u32 tab;                    /* result: byte offset of the table from ws */
+};
+
+/* Build the decode table of a complete canonical code (construct():
+ * yeast.c:246-278) from count[] and the symbols already in canonical order at
+ * ws+YS_WS_SORT.  The sub-table width is the smallest one that the remaining
+ * counts can fill. */
+DEV void build_table(Hdr &h, const Cnt16 &count)
+{
+    h.tab = YS_WS_ARENA + h.arena_used;
+    if (h.arena_used + YS_TAB_ENTRIES * 2 > h.arena_size) {
+        rd_fail(h.r, YS_WORKSPACE);
+        h.tab = YS_WS_ARENA;
+        return;
+    }
+    u16 *t = (u16 *)(h.ws + h.tab);
+    const u16 *sorted = (const u16 *)(h.ws + YS_WS_SORT);
+
+    if (cnt_get(count, 0)) { /* one symbol, zero bits */
+        u32 e = (u32)sorted[0] << 4;
+        u64 e4 = (u64)e * 0x0001000100010001ull;
+        for (u32 i = 0; i < 64; i++)
+            ((u64 *)t)[i] = e4;
+        h.arena_used += 512;
+        return;
+    }
+    Cnt16 left = count; /* codes not yet placed, per length */
+    u32 code = 0;       /* canonical code, MSB first, of the current length */
+    u32 si = 0;
+    u32 total = 256; /* entries used */
+    u32 sub_base = 0, sub_bits = 0, sub_key = 0xffffffffu;
+    for (u32 len = 1; len <= 15; len++) {
+        code <<= 1;
+        u32 n = cnt_get(count, len);
+        for (u32 k = 0; k < n; k++, si++, code++) {
+            u32 s = sorted[si];
+            u32 rev = __builtin_bitreverse32(code) >> (32 - len); /* stream bit order */
+            u32 e = (s << 4) | len;
+            if (len <= ROOT) {
+                for (u32 i = rev; i < 256; i += 1u << len)
+                    t[i] = (u16)e;
+            } else {
+                u32 key = rev & 255;
+                if (key != sub_key) { /* open the next sub-table */
+                    sub_key = key;
+                    sub_base = total;
+                    u32 l2 = len;
+                    i64 room = (i64)1 << (l2 - ROOT);
+                    while (l2 < 15) {
+                        room -= cnt_get(left, l2);
+                        if (room <= 0)
+                            break;
+                        l2++;
+                        room <<= 1;
+                    }
+                    sub_bits = l2 - ROOT;
+                    total += 1u << sub_bits;
+                    if (total > YS_TAB_ENTRIES) { /* cannot happen for a complete code */
+                        rd_fail(h.r, YS_WORKSPACE);
+                        return;
+                    }
+                    t[key] = (u16)((sub_base << 4) | (ROOT + sub_bits));
+                }
+                for (u32 i = rev >> ROOT; i < (1u << sub_bits); i += 1u << (len - ROOT))
+                    t[sub_base + i] = (u16)e;
+            }
+            cnt_dec(left, len);
+        }
+    }
+    h.arena_used += (total * 2 + 15) & ~15u;
+}
+
+/* read_code(): prefix() yeast.c:361-542.  num = alphabet size.  Leaves the
+   table offset in h.tab (always a readable table, even after a failure). */
+NOINL Hdr read_code(Hdr h, u32 num)
+{
+    Rd &r = h.r;
+    u16 *sorted = (u16 *)(h.ws + YS_WS_SORT);
+    h.tab = YS_WS_ARENA;
+    u32 hskip = take(r, 2);
+    Cnt16 count;
+    cnt_clear(count);
+
+    if (hskip == 1) { /* simple code, yeast.c:372-403 and simple() :307-348 */
+        u32 abits = 32 - __builtin_clz(num - 1);
+        u32 nsym = take(r, 2) + 1;
+        u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (u32 k = 0; k < nsym; k++) {
+            u32 v = take(r, abits);
+            if (v >= num) {
+                rd_fail(r, YS_INVALID); /* :393 */
+                return h;
+            }
+            if (k == 0) s0 = v;
+            else if (k == 1) s1 = v;
+            else if (k == 2) s2 = v;
+            else s3 = v;
+        }
+        u32 shape = nsym;
+        if (nsym == 4)
+            shape += take(r, 1);
+        if (r.rc)
+            return h;
+#define ORD(a, b) do { if (a > b) { u32 t_ = a; a = b; b = t_; } } while (0)
+        switch (shape) {
+        case 1: cnt_add(count, 0, 1); break;
+        case 2: cnt_add(count, 1, 2); ORD(s0, s1); break;
+        case 3: cnt_add(count, 1, 1); cnt_add(count, 2, 2); ORD(s1, s2); break;
+        case 4:
+            cnt_add(count, 2, 4);
+            ORD(s0, s1); ORD(s2, s3); ORD(s0, s2); ORD(s1, s3); ORD(s1, s2);
+            break;
+        default:
+            cnt_add(count, 1, 1); cnt_add(count, 2, 1); cnt_add(count, 3, 2);
+            ORD(s2, s3);
+        }
+#undef ORD
+        sorted[0] = (u16)s0; sorted[1] = (u16)s1; sorted[2] = (u16)s2; sorted[3] = (u16)s3;
+        build_table(h, count);
+        return h;
+    }
+
+    /* ---- complex code: first the code length code, yeast.c:429-461 ---- */
+    /* fixed code for the code length code lengths (yeast.c:422), indexed by 4 stream bits */
+    const u64 FIX_SYM = 0x5340234013402340ull; /* entry i at bits 4i: symbol */
+    const u64 FIX_LEN = 0x4222322242223222ull; /* entry i at bits 4i: length */
+    u64 clen = 0; /* 18 x 3-bit code length code lengths */
+    int space = 32;
+    u32 nonzero = 0, lastsym = 0;
+    u32 nsym = hskip;
+    /* order[] of yeast.c:415-417 packed 5 bits each */
+    const u64 ORD_LO = (1ull) | (2ull << 5) | (3ull << 10) | (4ull << 15) | (0ull << 20) | (5ull << 25) |
+                       (17ull << 30) | (6ull << 35) | (16ull << 40) | (7ull << 45) | (8ull << 50) | (9ull << 55);
+    const u64 ORD_HI = (10ull) | (11ull << 5) | (12ull << 10) | (13ull << 15) | (14ull << 20) | (15ull << 25);
+    while (nsym < 18) {
+        rd_refill(r);
+        u32 pk = (u32)r.w & 15;
+        u32 l = (u32)(FIX_LEN >> (pk * 4)) & 15;
+        u32 s = (u32)(FIX_SYM >> (pk * 4)) & 15;
+        if (r.pos + l > r.nbits) {
+            if (!r.rc) {
+                r.rc = YS_EOF;
+                r.dry = 1;
+            }
+            r.nbits = 0;
+            return h;
+        }
+        r.w >>= l; r.have -= l; r.pos += l;
+        u32 k = nsym < 12 ? (u32)(ORD_LO >> (nsym * 5)) & 31 : (u32)(ORD_HI >> ((nsym - 12) * 5)) & 31;
+        nsym++;
+        clen |= (u64)s << (k * 3);
+        if (s) {
+            nonzero++;
+            lastsym = k;
+            space -= 32 >> s;
+            if (space <= 0)
+                break;
+        }
+    }
+    if (space < 0 || (space && nonzero != 1)) {
+        rd_fail(r, YS_INVALID); /* over-subscribed :451 / incomplete :453 code length code */
+        return h;
+    }
+
+    /* decode table of the code length code: 32 entries x 8 bits (sym<<3 | len) in registers */
+    u64 q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (space) { /* single symbol, zero bits :456-459 */
+        u64 e = (u64)(lastsym << 3) * 0x0101010101010101ull;
+        q0 = q1 = q2 = q3 = e;
+    } else {
+        u32 code = 0;
+        for (u32 len = 1; len <= 5; len++) {
+            code <<= 1;
+            for (u32 s = 0; s < 18; s++) {
+                if (((u32)(clen >> (s * 3)) & 7) != len)
+                    continue;
+                u32 rev = __builtin_bitreverse32(code) >> (32 - len);
+                u64 e = (u64)((s << 3) | len);
+                for (u32 i = rev; i < 32; i += 1u << len) {
+                    u64 m = e << ((i & 7) * 8);
+                    u32 q = i >> 3;
+                    q0 |= q == 0 ? m : 0;
+                    q1 |= q == 1 ? m : 0;
+                    q2 |= q == 2 ? m : 0;
+                    q3 |= q == 3 ? m : 0;
+                }
+                code++;
+            }
+        }
+    }
+
+    /* ---- the code lengths themselves, yeast.c:464-518 ---- */
+    if (h.arena_used + 704 + 16 + YS_TAB_ENTRIES * 2 > h.arena_size) {
+        rd_fail(r, YS_WORKSPACE);
+        return h;
+    }
+    u8 *lens = (u8 *)(h.ws + YS_WS_ARENA + h.arena_used); /* scratch where the table will go */
+    int left = 1 << 15;
+    u32 prev = 8, rep = 0, zeros = 0, n;
+    nsym = 0;
+    do {
+        rd_refill(r);
+        u32 pk = (u32)r.w & 31;
+        u32 q = pk >> 3;
+        u64 x = q == 0 ? q0 : q == 1 ? q1 : q == 2 ? q2 : q3;
+        u32 e = (u32)(x >> ((pk & 7) * 8)) & 255;
+        u32 l = e & 7;
+        if (r.pos + l > r.nbits) {
+            if (!r.rc) {
+                r.rc = YS_EOF;
+                r.dry = 1;
+            }
+            r.nbits = 0;
+            return h;
+        }
+        r.w >>= l; r.have -= l; r.pos += l;
+        u32 len = e >> 3;
+        if (len < 16) {
+            lens[nsym++] = (u8)len;
+            if (len) {
+                left -= (1 << 15) >> len;
+                prev = len;
+                cnt_add(count, len, 1);
+            }
+            rep = 0;
+            zeros = 0;
+        } else if (len == 16) {
+            n = rep;
+            rep = (rep ? (rep - 2) << 2 : 0) + 3 + take(r, 2);
+            n = rep - n;
+            if (r.rc)
+                return h;
+            if (nsym + n > num) {
+                rd_fail(r, YS_INVALID); /* too many repeats :491 */
+                return h;
+            }
+            left -= (int)n * ((1 << 15) >> prev);
+            if (left < 0)
+                break;
+            cnt_add(count, prev, n);
+            for (u32 k = 0; k < n; k++)
+                lens[nsym++] = (u8)prev;
+            zeros = 0;
+        } else {
+            n = zeros;
+            zeros = (zeros ? (zeros - 2) << 3 : 0) + 3 + take(r, 3);
+            n = zeros - n;
+            if (r.rc)
+                return h;
+            if (nsym + n > num) {
+                rd_fail(r, YS_INVALID); /* too many repeats :508 */
+                return h;
+            }
+            for (u32 k = 0; k < n; k++)
+                lens[nsym++] = 0;
+            rep = 0;
+        }
+    } while (left > 0 && nsym < num);
+    if (left != 0) {
+        rd_fail(r, YS_INVALID); /* incomplete :516 / over-subscribed :518 code */
+        return h;
+    }
+
+    /* counting sort into canonical order (construct() yeast.c:266-277) */
+    Cnt16 offs;
+    cnt_clear(offs);
+    {
+        u32 acc = 0;
+        for (u32 l = 1; l <= 15; l++) {
+            cnt_add(offs, l, acc);
+            acc += cnt_get(count, l);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (u32 s = 0; s < nsym; s++) {
+        u32 l = lens[s];
+        if (l) {
+            sorted[cnt_get(offs, l)] = (u16)s;
+            cnt_add(offs, l, 1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    build_table(h, count);
+    return h;
+}
+
+/* block_types(): yeast.c:576-584 */
+DEV u32 read_count256(Rd &r)
+{
+    if (!take(r, 1))
+        return 1;
+    u32 k = take(r, 3);
+    return 1 + (1u << k) + take(r, k);
+}
+
+/* block_length(): yeast.c:550-567; base[]/extra[] from their closed form */
+DEV u32 read_block_count(Rd &r, const u16 *t)
+{
+    u32 s = dec_sym(r, t);
+    u32 base, extra;
+    if (s < 4) { base = 1 + 4 * s; extra = 2; }
+    else if (s < 8) { base = 17 + 8 * (s - 4); extra = 3; }
+    else if (s < 12) { base = 49 + 16 * (s - 8); extra = 4; }
+    else if (s < 16) { base = 113 + 32 * (s - 12); extra = 5; }
+    else if (s < 18) { base = 241 + 64 * (s - 16); extra = 6; }
+    else if (s >= 25) { base = 16625; extra = 24; }
+    else { extra = s - 11; base = 369 + ((1u << (s - 11)) - 128); }
+    return base + take(r, extra);
+}
+
+/* context_map(): yeast.c:589-647.  map has room for len bytes. */
+NOINL Hdr read_context_map(Hdr h, u8 *map, u32 len, u32 trees)
+{
+    Rd &r = h.r;
+    u32 rlemax = 0;
+    if (take(r, 1))
+        rlemax = 1 + take(r, 4);
+    u32 save = h.arena_used;
+    h = read_code(h, rlemax + trees);
+    const u16 *t = (const u16 *)(h.ws + h.tab);
+    h.arena_used = save; /* the map's own code is dead once the map is read */
+    if (r.rc)
+        return h;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    u32 n = 0;
+    do {
+        u32 s = dec_sym(r, t);
+        if (r.rc)
+            return h;
+        if (s == 0)
+            map[n++] = 0;
+        else if (s <= rlemax) {
+            u32 z = (1u << s) + take(r, s);
+            if (r.rc)
+                return h;
+            if (n + z > len) {
+                rd_fail(r, YS_INVALID); /* run length too long :616 */
+                return h;
+            }
+            for (u32 k = 0; k < z; k++)
+                map[n++] = 0;
+        } else
+            map[n++] = (u8)(s - rlemax);
+    } while (n < len);
+    if (take(r, 1)) { /* inverse move-to-front :629-646 */
+        u8 *tab = h.ws + YS_WS_MTF;
+        for (u32 k = 0; k < trees; k++)
+            tab[k] = (u8)k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (n = 0; n < len; n++) {
+            u32 s = map[n];
+            if (s >= trees)
+                s = 0; /* unreachable for a valid map; keeps the list index in range */
+            if (s) {
+                u8 front = tab[s];
+                for (u32 k = s; k; k--)
+                    tab[k] = tab[k - 1];
+                tab[0] = front;
+                map[n] = front;
+            } else
+                map[n] = tab[0];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return h;
+}
+
+/* ------------------------------------------------------------------ state */
+
+struct Blk { /* one block category: yeast.c:112-123 */
+    u32 num, type, prev, left;
+    u32 t_type, t_count; /* byte offsets of the two block-switch tables from ws */
+};
+
+struct Ctx {
+    Rd r;
+    const u8 *src;
+    u8 *out;
+    u64 got, cap;
+    u32 wsize;
+    u32 r0, r1, r2, r3; /* last four distances, r0 most recent (ring[] yeast.c:126) */
+    u32 postfix, direct;
+    Blk L, I, D;
+    u32 lit_codes, dist_codes;
+    u8 *ws;
+    u32 arena_size;
+    u32 p1, p2, ctx_stale;
+    u32 nmeta;
+    u64 need; /* output bytes required when rc == YS_CAPACITY */
+    const u8 *dict, *xf;
+    const Shared *sh;
+};
+
+DEV const u16 *tab_at(const Ctx &c, u32 off) { return (const u16 *)(c.ws + off); }
+
+/* one category's NBLTYPES header: yeast.c:1079-1118 */
+DEV void read_block_header(Ctx &c, Hdr &h, Blk &k)
+{
+    k.prev = 1;
+    k.type = 0;
+    k.left = 0xffffffffu;
+    k.t_type = k.t_count = YS_WS_ARENA;
+    k.num = read_count256(h.r);
+    if (k.num > 1) {
+        h = read_code(h, k.num + 2);
+        k.t_type = h.tab;
+        h = read_code(h, 26);
+        k.t_count = h.tab;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        k.left = read_block_count(h.r, (const u16 *)(h.ws + k.t_count));
+    }
+}
+
+/* block switch: yeast.c:1168-1180 */
+DEV void switch_block(Ctx &c, Blk &k)
+{
+    u32 n = dec_sym(c.r, tab_at(c, k.t_type));
+    n = n > 1 ? n - 2 : n ? (k.type + 1 == k.num ? 0 : k.type + 1) : k.prev;
+    if (n >= k.num)
+        n = 0; /* only reachable after a read failure; keeps table indices in range */
+    k.prev = k.type;
+    k.type = n;
+    k.left = read_block_count(c.r, tab_at(c, k.t_count));
+}
+
+/* context_id(): yeast.c:698-755 */
+DEV u32 context_id(const Ctx &c, u32 p1, u32 p2, u32 mode)
+{
+    const u8 *lut = c.sh->lut;
+    switch (mode) {
+    case 0: return p1 & 0x3f;
+    case 1: return p1 >> 2;
+    case 2: return lut[p1] | lut[256 + p2];
+    default: return ((u32)lut[512 + p1] << 3) | lut[512 + p2];
+    }
+}
+
+/* ------------------------------------------------------------ byte movers */
+
+template <int G>
+DEV u32 group_min(u32 v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        u32 t = __shfl_xor(v, o, G);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+/* LZ77 copy of n bytes from distance d (yeast.c:1285-1293): byte-serial
+   semantics, so an overlapping copy repeats its first d bytes. */
+template <int G, bool CMP>
+DEV void emit_copy(Ctx &c, u32 n, u64 d, u32 sub)
+{
+    u8 *dst = c.out + c.got;
+    const u8 *from = dst - d;
+    if (CMP) {
+        /* every byte is compared with the expected data itself d bytes back */
+        u32 bad = 0xffffffffu;
+        for (u32 i = sub; i < n; i += G)
+            if (dst[i] != from[i] && i < bad)
+                bad = i;
+        bad = group_min<G>(bad);
+        if (bad != 0xffffffffu) {
+            c.got += bad;
+            rd_fail(c.r, YS_MISMATCH);
+            return;
+        }
+        c.got += n;
+        return;
+    }
+    if (d >= n) { /* disjoint: 8-byte units spread over the lanes, then the tail */
+        u32 n8 = n >> 3;
+        for (u32 j = sub; j < n8; j += G) {
+            u64 v;
+            __builtin_memcpy(&v, from + 8 * j, 8);
+            __builtin_memcpy(dst + 8 * j, &v, 8);
+        }
+        for (u32 i = (n8 << 3) + sub; i < n; i += G)
+            dst[i] = from[i];
+    } else if (G == 1 && d >= 8) {
+        u32 i = 0;
+        for (; i + 8 <= n; i += 8) {
+            u64 v;
+            __builtin_memcpy(&v, from + i, 8);
+            __builtin_memcpy(dst + i, &v, 8);
+        }
+        for (; i < n; i++)
+            dst[i] = from[i];
+    } else { /* overlapping: byte i repeats byte i mod d of the source */
+        u32 dd = (u32)d;
+        u32 m = sub % dd, step = G % dd;
+        for (u32 i = sub; i < n; i += G) {
+            dst[i] = from[m];
+            m += step;
+            if (m >= dd)
+                m -= dd;
+        }
+    }
+    c.got += n;
+}
+
+/* dict_word(): yeast.c:908-949 with the elementary transforms :799-879.
+   Byte k of the result is computed independently by whichever lane owns it. */
+template <int G, bool CMP>
+DEV void emit_dict(Ctx &c, u32 copy, u64 id, u32 &mlen, u32 sub)
+{
+    if (copy > 24 || copy < 4) {
+        rd_fail(c.r, YS_INVALID); /* :921-924 */
+        return;
+    }
+    /* NDBITS (yeast.c:916-919), 4 bits per length */
+    const u64 NDB_LO = (10ull << 16) | (10ull << 20) | (11ull << 24) | (11ull << 28) | (10ull << 32) |
+                       (10ull << 36) | (10ull << 40) | (10ull << 44) | (10ull << 48) | (9ull << 52) |
+                       (9ull << 56) | (8ull << 60);                /* lengths 4..15 at bits 4*len */
+    const u64 NDB_HI = 7ull | (7ull << 4) | (8ull << 8) | (7ull << 12) | (7ull << 16) | (6ull << 20) |
+                       (6ull << 24) | (5ull << 28) | (5ull << 32); /* lengths 16..24 */
+    u32 nd = copy < 16 ? (u32)(NDB_LO >> (copy * 4)) & 15 : (u32)(NDB_HI >> ((copy - 16) * 4)) & 15;
+    u64 xform = id >> nd;
+    if (xform >= 121) {
+        rd_fail(c.r, YS_INVALID); /* :929-930 */
+        return;
+    }
+    u32 index = (u32)id & ((1u << nd) - 1);
+    /* DOFFSET[len] (yeast.c:911-915) = sum over l < len of l << NDBITS[l] */
+    u32 doff = 0;
+    for (u32 l = 4; l < copy; l++) {
+        u32 b = l < 16 ? (u32)(NDB_LO >> (l * 4)) & 15 : (u32)(NDB_HI >> ((l - 16) * 4)) & 15;
+        doff += l << b;
+    }
+    const u8 *w = c.dict + doff + index * copy;
+    const u8 *t = c.xf + 20 * (u32)xform;
+    u32 hdr;
+    __builtin_memcpy(&hdr, t, 4);
+    u32 op = hdr & 255, omit = (hdr >> 8) & 255, plen = (hdr >> 16) & 255, slen = hdr >> 24;
+    u32 wlen = copy, wskip = 0;
+    if (op == 3) { /* omit first */
+        wlen = copy > omit ? copy - omit : 0;
+        wskip = wlen ? omit : 0;
+    } else if (op == 4)
+        wlen = copy > omit ? copy - omit : 0;
+    u32 total = plen + wlen + slen;
+    if (total > mlen) {
+        rd_fail(c.r, YS_INVALID); /* :1269 */
+        return;
+    }
+    /* uppercase masks: bit j set -> word byte j is xor-ed with 32 / with 5 */
+    u32 x32 = 0, x5 = 0;
+    if (op == 1 || op == 2) {
+        u32 j = 0;
+        do {
+            u32 ch = w[j];
+            if (ch < 192) {
+                if (ch >= 97 && ch <= 122)
+                    x32 |= 1u << j;
+                j += 1;
+            } else if (ch < 224) {
+                if (j + 1 < copy)
+                    x32 |= 1u << (j + 1);
+                j += 2;
+            } else {
+                if (j + 2 < copy)
+                    x5 |= 1u << (j + 2);
+                j += 3;
+            }
+        } while (op == 2 && j < copy);
+    }
+    u8 *dst = c.out + c.got;
+    u32 bad = 0;
+    for (u32 k = sub; k < total; k += G) {
+        u32 v;
+        if (k < plen)
+            v = t[4 + k];
+        else if (k < plen + wlen) {
+            u32 j = k - plen + wskip;
+            v = w[j];
+            v ^= ((x32 >> j) & 1) << 5;
+            v ^= ((x5 >> j) & 1) * 5;
+        } else
+            v = t[12 + k - plen - wlen];
+        if (CMP)
+            bad |= dst[k] != v;
+        else
+            dst[k] = (u8)v;
+    }
+    if (CMP) {
+        if (__any(bad)) { /* whole-wave vote: CMP is only instantiated with G == 64 */
+            rd_fail(c.r, YS_MISMATCH); /* memcmp semantics: got stays at the start of the word :1271 */
+            return;
+        }
+    }
+    c.got += total;
+    mlen -= total;
+}
+
+/* stored block (yeast.c:1061-1070) */
+template <int G, bool CMP>
+DEV void emit_raw(Ctx &c, const u8 *from, u32 n, u32 sub)
+{
+    u8 *dst = c.out + c.got;
+    if (CMP) {
+        u32 bad = 0;
+        for (u32 i = sub; i < n; i += G)
+            bad |= dst[i] != from[i];
+        if (__any(bad)) {
+            rd_fail(c.r, YS_MISMATCH); /* memcmp over the block: got unchanged :1063 */
+            return;
+        }
+    } else {
+        u32 n8 = n >> 3;
+        for (u32 j = sub; j < n8; j += G) {
+            u64 v;
+            __builtin_memcpy(&v, from + 8 * j, 8);
+            __builtin_memcpy(dst + 8 * j, &v, 8);
+        }
+        for (u32 i = (n8 << 3) + sub; i < n; i += G)
+            dst[i] = from[i];
+    }
+    c.got += n;
+}
+
+/* the bytes a group has just written become visible to its own later loads */
+DEV void group_sync_mem() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+/* ------------------------------------------------------------- meta-block */
+
+/* metablock(): yeast.c:971-1308.  Returns ISLAST. */
+template <int G, bool CMP>
+DEV u32 metablock(Ctx &c, u32 sub)
+{
+    Rd &r = c.r;
+    u32 last = take(r, 1);
+    if (last && take(r, 1)) { /* ISLASTEMPTY :993 */
+        if (!r.rc && tail_nonzero(r))
+            rd_fail(r, YS_INVALID);
+        return 1;
+    }
+    u32 n = take(r, 2); /* MNIBBLES - 4 */
+    if (r.rc)
+        return 1;
+    if (n == 3) { /* metadata :1008-1032 */
+        if (take(r, 1)) {
+            rd_fail(r, YS_INVALID);
+            return 1;
+        }
+        n = take(r, 2);
+        u32 skip = n ? take(r, n << 3) + 1 : 0;
+        if (r.rc)
+            return 1;
+        if ((n > 1 && (skip >> ((n - 1) << 3)) == 0) || tail_nonzero(r)) {
+            rd_fail(r, YS_INVALID);
+            return 1;
+        }
+        u64 pos = (r.pos + 7) & ~(u64)7;
+        r.pos = pos;
+        if ((u64)skip * 8 > r.nbits - pos) {
+            rd_fail(r, YS_EOF); /* :1025, nothing more consumed */
+            return 1;
+        }
+        rd_seek(r, c.src, pos + (u64)skip * 8);
+        return last;
+    }
+    u32 mlen = 1 + take(r, 16);
+    if (n) {
+        mlen += take(r, n << 2) << 16;
+        if (!r.rc && (mlen >> ((n + 3) << 2)) == 0)
+            rd_fail(r, YS_INVALID); /* :1037 */
+    }
+    if (r.rc)
+        return 1;
+    if (c.got + mlen > c.cap) { /* :1040-1047 */
+        c.need = c.got + mlen;
+        rd_fail(r, CMP ? YS_MISMATCH : YS_CAPACITY);
+        return 1;
+    }
+    if (!last && take(r, 1)) { /* ISUNCOMPRESSED :1050 */
+        if (tail_nonzero(r)) {
+            rd_fail(r, YS_INVALID);
+            return 1;
+        }
+        u64 pos = (r.pos + 7) & ~(u64)7;
+        r.pos = pos;
+        if ((u64)mlen * 8 > r.nbits - pos) {
+            rd_fail(r, YS_EOF); /* :1059 */
+            return 1;
+        }
+        emit_raw<G, CMP>(c, c.src + (pos >> 3), mlen, sub);
+        if (r.rc)
+            return 1;
+        rd_seek(r, c.src, pos + (u64)mlen * 8);
+        c.ctx_stale = 1;
+        return last;
+    }
+    if (r.rc)
+        return 1;
+
+    /* ---- header: yeast.c:1078-1159 ---- */
+    Hdr h;
+    h.r = r;
+    h.ws = c.ws;
+    h.arena_used = 0;
+    h.arena_size = c.arena_size;
+    h.tab = YS_WS_ARENA;
+    read_block_header(c, h, c.L);
+    read_block_header(c, h, c.I);
+    read_block_header(c, h, c.D);
+    c.postfix = take(h.r, 2);
+    c.direct = take(h.r, 4) << c.postfix;
+    u32 dists = 16 + c.direct + (48u << c.postfix);
+    u8 *mode = c.ws + YS_WS_MODE;
+    for (n = 0; n < c.L.num; n++)
+        mode[n] = (u8)take(h.r, 2);
+    c.lit_codes = read_count256(h.r);
+    /* literal context map (u8 per entry) and literal table map (u32 per entry) */
+    u32 nmap = c.lit_codes > 1 ? (c.L.num << 6) : 0;
+    if (h.arena_used + nmap * 5 + 32 > h.arena_size)
+        rd_fail(h.r, YS_WORKSPACE);
+    if (h.r.rc) {
+        r = h.r;
+        return 1;
+    }
+    u8 *lit_map = c.ws + YS_WS_ARENA + h.arena_used;
+    h.arena_used += (nmap + 15) & ~15u;
+    u32 *lit_tab = (u32 *)(c.ws + YS_WS_ARENA + h.arena_used);
+    h.arena_used += nmap * 4;
+    if (c.lit_codes > 1)
+        h = read_context_map(h, lit_map, nmap, c.lit_codes);
+    c.dist_codes = read_count256(h.r);
+    u8 *dist_map = c.ws + YS_WS_DMAP;
+    if (c.dist_codes > 1 && !h.r.rc)
+        h = read_context_map(h, dist_map, c.D.num << 2, c.dist_codes);
+
+    u32 *ldir = (u32 *)(c.ws + YS_WS_LDIR), *ddir = (u32 *)(c.ws + YS_WS_DDIR);
+    u32 *itab = (u32 *)(c.ws + YS_WS_ITAB), *dtab = (u32 *)(c.ws + YS_WS_DTAB);
+    for (n = 0; n < c.lit_codes && !h.r.rc; n++) {
+        h = read_code(h, 256);
+        ldir[n] = h.tab;
+    }
+    for (n = 0; n < c.I.num && !h.r.rc; n++) {
+        h = read_code(h, 704);
+        itab[n] = h.tab;
+    }
+    for (n = 0; n < c.dist_codes && !h.r.rc; n++) {
+        h = read_code(h, dists);
+        ddir[n] = h.tab;
+    }
+    r = h.r;
+    if (r.rc)
+        return 1;
+    group_sync_mem();
+    /* resolve the context maps to table offsets once */
+    u32 tL0 = ldir[0], tD0 = ddir[0];
+    for (n = 0; n < nmap; n++)
+        lit_tab[n] = ldir[lit_map[n]];
+    if (c.dist_codes > 1)
+        for (n = 0; n < (c.D.num << 2); n++)
+            dtab[n] = ddir[dist_map[n]];
+    group_sync_mem();
+    const u16 *tI = tab_at(c, itab[0]);
+    u32 cur_mode = mode[0];
+    const u32 *len_tab = c.sh->len_tab;
+
+    /* ---- command loop: yeast.c:1166-1295 ---- */
+    do {
+        if (c.I.num > 1) {
+            if (c.I.left == 0) {
+                switch_block(c, c.I);
+                tI = tab_at(c, itab[c.I.type]);
+            }
+            c.I.left--;
+        }
+        u32 cmd = dec_sym(r, tI);
+        /* cell -> insert/copy code offsets, map[] of yeast.c:655 and :678, 5 bits a cell */
+        const u64 ICELL = 0ull | (0ull << 5) | (0ull << 10) | (0ull << 15) | (8ull << 20) | (8ull << 25) |
+                          (0ull << 30) | (16ull << 35) | (8ull << 40) | (16ull << 45) | (16ull << 50);
+        const u64 CCELL = 0ull | (8ull << 5) | (0ull << 10) | (8ull << 15) | (0ull << 20) | (8ull << 25) |
+                          (16ull << 30) | (0ull << 35) | (16ull << 40) | (8ull << 45) | (16ull << 50);
+        u32 cell = (cmd >> 6) & 15;
+        u32 ie = len_tab[((u32)(ICELL >> (cell * 5)) & 31) + ((cmd >> 3) & 7)];
+        u32 ce = len_tab[24 + ((u32)(CCELL >> (cell * 5)) & 31) + (cmd & 7)];
+        u32 insert = (ie & 0xffff) + take(r, ie >> 16);
+        u32 copy = (ce & 0xffff) + take(r, ce >> 16);
+        if (r.rc)
+            break;
+        if (insert > mlen) {
+            rd_fail(r, YS_INVALID); /* :1189 */
+            break;
+        }
+        mlen -= insert;
+        if (insert) {
+            if (c.ctx_stale && c.lit_codes > 1) {
+                group_sync_mem();
+                c.p1 = c.got ? c.out[c.got - 1] : 0;
+                c.p2 = c.got > 1 ? c.out[c.got - 2] : 0;
+            }
+            c.ctx_stale = 0;
+            do {
+                if (c.L.num > 1) {
+                    if (c.L.left == 0) {
+                        switch_block(c, c.L);
+                        cur_mode = mode[c.L.type];
+                    }
+                    c.L.left--;
+                }
+                u32 tl = tL0;
+                if (c.lit_codes > 1)
+                    tl = lit_tab[(c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode)];
+                u32 s = dec_sym(r, tab_at(c, tl));
+                if (r.rc)
+                    break;
+                if (CMP) {
+                    u32 e = c.out[c.got];
+                    c.got++; /* yeast.c:1217: got advances before the compare throws */
+                    if (e != s) {
+                        rd_fail(r, YS_MISMATCH);
+                        break;
+                    }
+                } else {
+                    c.out[c.got] = (u8)s;
+                    c.got++;
+                }
+                c.p2 = c.p1;
+                c.p1 = s;
+            } while (--insert);
+            if (r.rc)
+                break;
+        }
+        if (mlen == 0)
+            break;
+
+        u64 max = c.got > c.wsize ? c.wsize : c.got;
+        i64 dist;
+        if (cmd < 128)
+            dist = c.r0;
+        else {
+            if (c.D.num > 1) {
+                if (c.D.left == 0)
+                    switch_block(c, c.D);
+                c.D.left--;
+            }
+            u32 td = tD0;
+            if (c.dist_codes > 1)
+                td = dtab[(c.D.type << 2) + (copy > 4 ? 3 : copy - 2)];
+            u32 ds = dec_sym(r, tab_at(c, td));
+            /* distance(): yeast.c:761-789 */
+            if (ds < 16) {
+                u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
+                u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
+                int dl = 0;
+                if (ds >= 4) {
+                    u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
+                    dl = (int)(k >> 1) + 1;
+                    if (!(k & 1))
+                        dl = -dl;
+                }
+                dist = (i64)rv + dl;
+            } else if (ds < 16 + c.direct)
+                dist = ds - 15;
+            else {
+                u32 nn = ds - c.direct - 16;
+                u32 x = 1 + (nn >> (c.postfix + 1));
+                if (x > 25)
+                    x = 25; /* only after a read failure */
+                u64 off = ((u64)(2 + ((nn >> c.postfix) & 1)) << x) - 4;
+                dist = (i64)(((off + take(r, x)) << c.postfix) + (nn & ((1u << c.postfix) - 1)) + c.direct + 1);
+            }
+            if (r.rc)
+                break;
+            if (ds && dist > 0 && (u64)dist <= max) {
+                c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
+            }
+        }
+        if (dist <= 0) {
+            rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
+            break;
+        }
+        if ((u64)dist > max) {
+            emit_dict<G, CMP>(c, copy, (u64)dist - max - 1, mlen, sub);
+        } else {
+            if (copy > mlen) {
+                rd_fail(r, YS_INVALID); /* :1283 */
+                break;
+            }
+            mlen -= copy;
+            emit_copy<G, CMP>(c, copy, (u64)dist, sub);
+        }
+        c.ctx_stale = 1;
+    } while (mlen && !r.rc);
+    if (!r.rc && last && tail_nonzero(r))
+        rd_fail(r, YS_INVALID); /* :1305 */
+    return last;
+}
+
+/* yeast(): yeast.c:1353-1400 for one stream of the batch */
+template <int G, bool CMP>
+DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub)
+{
+    Ctx c;
+    u64 s0 = p.src_off[job], s1 = p.src_off[job + 1];
+    u64 d0 = p.dst_off[job], d1 = p.dst_off[job + 1];
+    c.src = p.src + s0;
+    c.out = p.dst + d0;
+    c.cap = d1 - d0;
+    c.got = 0;
+    c.r.rc = YS_OK;
+    c.r.dry = 0;
+    c.r.nbits = (s1 - s0) * 8;
+    c.r0 = 4; c.r1 = 11; c.r2 = 15; c.r3 = 16; /* :1327-1331, most recent first */
+    c.ws = ws;
+    c.arena_size = (u32)(p.ws_stride - YS_WS_ARENA);
+    c.p1 = c.p2 = 0;
+    c.ctx_stale = 0;
+    c.nmeta = 0;
+    c.need = 0;
+    c.dict = p.dict;
+    c.xf = p.xforms;
+    c.sh = sh;
+    c.L.num = c.I.num = c.D.num = 1;
+    rd_seek(c.r, c.src, 0);
+
+    u32 wbits = 16;
+    if (take(c.r, 1)) { /* WBITS :1372-1378 */
+        u32 v = take(c.r, 3);
+        if (v)
+            wbits = v + 17;
+        else {
+            v = take(c.r, 3);
+            wbits = v ? v + 8 : 17;
+        }
+    }
+    if (!c.r.rc && wbits == 9)
+        rd_fail(c.r, YS_INVALID);
+    c.wsize = (1u << wbits) - 16;
+    while (!c.r.rc) {
+        u32 last = metablock<G, CMP>(c, sub);
+        if (c.r.rc)
+            break;
+        c.nmeta++;
+        if (last)
+            break;
+    }
+
+    ys_record rec;
+    rec.rc = (int32_t)c.r.rc;
+    rec.flags = wbits | ((c.nmeta > 0xffffff ? 0xffffffu : c.nmeta) << 8);
+    rec.got = c.got;
+    /* bytes pulled: every byte when the bit reader ran dry, else ceil(bits/8) (yeast.c:1388) */
+    rec.used = c.r.dry ? (s1 - s0) : (c.r.pos + 7) >> 3;
+    rec.check = c.need;
+    p.rec[job] = rec;
+    if (c.r.rc == YS_WORKSPACE && !p.retry && sub == 0)
+        p.retry_list[atomicAdd(p.retry_count, 1u)] = job;
+}
+
+template <int G, bool CMP>
+__global__ __launch_bounds__(256) void k_decode(ys_params p)
+{
+    __shared__ Shared sh;
+    for (u32 i = threadIdx.x; i < 768; i += blockDim.x)
+        sh.lut[i] = c_ctx_lut[i];
+    if (threadIdx.x < 48)
+        sh.len_tab[threadIdx.x] = c_len_tab[threadIdx.x];
+    __syncthreads();
+    u32 lane = threadIdx.x;
+    u32 sub = lane & (G - 1);
+    u32 gid = (blockIdx.x * blockDim.x + lane) / G;
+    u8 *ws = p.ws + (u64)gid * p.ws_stride;
+    for (;;) {
+        u32 job = 0;
+        if (sub == 0)
+            job = atomicAdd(p.counter, 1u);
+        if (G > 1)
+            job = __shfl(job, 0, G);
+        if (job >= (p.retry ? *p.retry_count : p.n))
+            break;
+        if (p.retry)
+            job = p.retry_list[job];
+        decode_stream<G, CMP>(p, job, ws, &sh, sub);
+    }
+}
+
+/* ---------------------------------------------------------------- launchers */
+
+extern "C" int ys_upload_constants(const u8 *lut768)
+{
+    /* insert_length()/copy_length() tables of yeast.c:658-665 and :681-688, from their structure:
+       each base is the previous base plus 1 << previous extra */
+    static const u8 ins_x[24] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 24};
+    static const u8 cpy_x[24] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 24};
+    u32 tab[48];
+    u32 b = 0;
+    for (int i = 0; i < 24; i++) {
+        tab[i] = b | ((u32)ins_x[i] << 16);
+        b += 1u << ins_x[i];
+    }
+    b = 2;
+    for (int i = 0; i < 24; i++) {
+        tab[24 + i] = b | ((u32)cpy_x[i] << 16);
+        b += 1u << cpy_x[i];
+    }
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_ctx_lut), lut768, 768);
+    if (e != hipSuccess)
+        return (int)e;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(c_len_tab), tab, sizeof(tab));
+}
+
+template <int G, bool CMP>
+static int launch_decode_t(const ys_params &p, u32 groups, hipStream_t st)
+{
+    u32 per_block = 256 / G;
+    u32 blocks = (groups + per_block - 1) / per_block;
+    hipLaunchKernelGGL((k_decode<G, CMP>), dim3(blocks), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+
+/* groups = number of resident groups (each owns one workspace slot) */
+extern "C" int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned groups, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (cmp)
+        return launch_decode_t<64, true>(*p, groups, st);
+    switch (lanes_per_stream) {
+    case 64: return launch_decode_t<64, false>(*p, groups, st);
+    case 16: return launch_decode_t<16, false>(*p, groups, st);
+    case 8: return launch_decode_t<8, false>(*p, groups, st);
+    case 4: return launch_decode_t<4, false>(*p, groups, st);
+    case 1: return launch_decode_t<1, false>(*p, groups, st);
+    }
+    return -1;
+}

@@ -22,7 +22,8 @@
 extern "C" {
 extern const unsigned char ys_dictionary[122784];
 extern const unsigned char ys_transforms[2420];
-int ys_upload_constants(const u8 *lut768, const u32 *x2n);
+int ys_upload_constants(const u8 *lut768);
+int ys_upload_check_constants(const u32 *x2n);
 int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned groups, void *stream);
 int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec, unsigned n, unsigned kind, u64 seed,
                     void *stream);
@@ -153,7 +154,9 @@ static int device_get(Device **out)
         x2n[0] = 0x40000000u;
         for (int k = 1; k < 68; k++)
             x2n[k] = crc_mul(x2n[k - 1], x2n[k - 1]);
-        int e = ys_upload_constants(g_luts, x2n);
+        int e = ys_upload_constants(g_luts);
+        if (!e)
+            e = ys_upload_check_constants(x2n);
         if (e)
             return fail("upload constants (is a gfx950 code object present?)", (hipError_t)e);
         HIPCK(hipMalloc((void **)&d.d_dict, sizeof(ys_dictionary)));
@@ -215,8 +218,8 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         lanes = env_int("YEAST_LANES", 8);
     if (cmp)
         lanes = 64;
-    if (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))) {
-        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: lanes_per_stream must be a power of two <= 64");
+    if (lanes != 1 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 64) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: lanes_per_stream must be 1, 4, 8, 16 or 64");
         return -1;
     }
     unsigned per_block = 256u / (unsigned)lanes;

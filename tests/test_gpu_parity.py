@@ -1,0 +1,176 @@
+"""GPU tier: the HIP path, called through the C-ABI, against the oracle and the golden fixtures.
+Bar: bit-exact output, identical return code, identical got/used."""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import brotli_amd as ba
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_yeast(src, expected=None):
+    rc, out, got, used = ba.yeast(src, expected)
+    return rc, got, used, out
+
+
+def test_native_library_is_loaded_and_sees_a_gpu():
+    assert os.path.exists(ba.LIB_PATH)
+    assert ba.lib().yeast_device_count() >= 1
+
+
+def test_crafted_good_and_bad_streams():
+    cr = H.load_json("crafted.json")
+    for name, v in cr.items():
+        src = bytes.fromhex(v["hex"])
+        rc, got, used, out = gpu_yeast(src)
+        assert (rc, got, used, out.hex()) == (v["rc"], v["got"], v["used"], v["out"]), name
+        assert (rc, got, used, out) == H.oracle_yeast(src), name
+
+
+def test_testdata_corpus_decode_mode():
+    idx = H.load_json("testdata.json")
+    for name, comp, orig in H.testdata_pairs():
+        rc, got, used, out = gpu_yeast(comp)
+        assert (rc, got, used) == (0, idx[name]["got"], idx[name]["used"]), name
+        assert out == orig, name
+
+
+def test_testdata_corpus_compare_mode():
+    # juxt.c:88 calls yeast(cmp=1); mismatch positions follow yeast.c:1217,1271,1287
+    for name, comp, orig in H.testdata_pairs():
+        assert gpu_yeast(comp, orig) == H.oracle_yeast(comp, orig), name
+        if len(orig) < 4:
+            continue
+        rnd = random.Random(len(orig))
+        for _ in range(4):
+            e = bytearray(orig)
+            e[rnd.randrange(len(e))] ^= 0x40
+            e = bytes(e)
+            assert gpu_yeast(comp, e) == H.oracle_yeast(comp, e), name
+        for cut in (1, len(orig) // 2):
+            assert gpu_yeast(comp, orig[:-cut]) == H.oracle_yeast(comp, orig[:-cut]), name
+        assert gpu_yeast(comp, orig + b"xx") == H.oracle_yeast(comp, orig + b"xx"), name
+    assert gpu_yeast(bytes.fromhex("06"), b"") == H.oracle_yeast(bytes.fromhex("06"), b"")
+
+
+def test_misc_encoder_parameters():
+    # window bits 10..24, qualities 0..10, NPOSTFIX/NDIRECT != 0 (unpinned by testdata/)
+    meta, streams = H.packed_streams("misc_streams")
+    res = ba.yeast_batch(streams, ba.CHECK_CRC32C)
+    for m, s, r in zip(meta["streams"], streams, res):
+        rc, got, used, out = H.oracle_yeast(s)
+        assert (r[0], r[2], r[3]) == (rc, got, used), m["params"]
+        assert r[1] == out, m["params"]
+        assert "%08x" % r[4] == m["crc32c"]
+
+
+@pytest.mark.parametrize("lanes", [64, 16, 8, 4, 1])
+def test_cfg2_batch_every_group_width(lanes, monkeypatch):
+    meta, streams = H.packed_streams("cfg2_streams")
+    monkeypatch.setenv("YEAST_LANES", str(lanes))
+    many = streams * 9  # 2,304 streams: above the threshold where the batch path picks YEAST_LANES
+    res = ba.yeast_batch(many, ba.CHECK_XXH64)
+    for i, r in enumerate(res):
+        m = meta["streams"][i % len(streams)]
+        assert (r[0], r[2], r[3]) == (0, m["got"], m["len"]), i
+        assert "%016x" % r[4] == m["xxh64"], i
+    for i in (0, 100, 255, 300, 2303):
+        assert res[i][1] == H.oracle_yeast(many[i])[3]
+
+
+def test_check_values_known_answers():
+    kat = H.load_json("checks.json")
+    alice = open(os.path.join(H.GOLD, "testdata", "alice29.txt"), "rb").read()
+    for k, v in kat.items():
+        data = (b"123456789" if k == "123456789" else b"" if k == "empty" else alice if k == "alice29.txt"
+                else alice[:int(k.split(":")[1][:-1])])
+        assert "%08x" % ba.crc32c(data) == v["crc32c"], k
+        assert "%08x" % ba.xxh32(data) == v["xxh32"], k
+        assert "%016x" % ba.xxh64(data) == v["xxh64"], k
+    o = H.oracle()
+    a = ba.crc32c(alice[:1000])
+    assert ba.crc32c(alice[1000:5000], a) == o.oracle_crc32c(0, alice[:5000], 5000)
+    assert ba.xxh64(alice[:777], 12345) == o.oracle_xxh64(alice[:777], 777, 12345)
+    assert ba.xxh32(alice[:777], 12345) == o.oracle_xxh32(alice[:777], 777, 12345)
+
+
+def test_fuzzed_streams_same_error_class_and_progress():
+    # truncations and bit flips of real streams: rc, got, used and the partial output must agree
+    rnd = random.Random(11)
+    meta, streams = H.packed_streams("cfg2_streams")
+    _, misc = H.packed_streams("misc_streams")
+    cases = []
+    for t in range(400):
+        base = streams[t % 7] if t % 3 else misc[t % len(misc)]
+        s = bytearray(base[:rnd.randrange(1, min(len(base), 6000))])
+        if t % 2:
+            for _ in range(rnd.randrange(1, 4)):
+                s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+        cases.append(bytes(s))
+    res = ba.yeast_batch(cases)
+    classes = set()
+    for s, r in zip(cases, res):
+        rc, got, used, out = H.oracle_yeast(s)
+        assert (r[0], r[2], r[3]) == (rc, got, used)
+        assert r[1] == out
+        classes.add(rc)
+    assert {2, 3} <= classes
+
+
+def test_full_size_batch_properties():
+    # BASELINE config 2 at full size: 65,536 streams, checked through size-independent properties
+    # (per-stream rc/got/used and a check-of-checks against the fixtures' reference values)
+    import torch
+    from brotli_amd.device import DeviceBatch
+    meta, distinct = H.packed_streams("cfg2_streams")
+    n = 65536
+    rng = np.random.RandomState(3)
+    order = rng.randint(0, len(distinct), size=n)
+    batch = DeviceBatch([distinct[j] for j in order], [65536] * n)
+    batch.decode(check=ba.CHECK_XXH64)
+    torch.cuda.synchronize()
+    r = batch.records()
+    ms = meta["streams"]
+    assert (r["rc"] == 0).all()
+    assert (r["got"] == np.array([ms[j]["got"] for j in order], dtype=np.uint64)).all()
+    assert (r["used"] == np.array([ms[j]["len"] for j in order], dtype=np.uint64)).all()
+    assert (r["check"] == np.array([int(ms[j]["xxh64"], 16) for j in order], dtype=np.uint64)).all()
+    for i in (0, 1, 4097, 65535):
+        assert batch.output(i) == H.oracle_yeast(distinct[order[i]])[3]
+    # second check kind over the same resident outputs, then a check of the checks
+    batch.check(ba.CHECK_CRC32C)
+    torch.cuda.synchronize()
+    r = batch.records()
+    want = np.array([int(ms[j]["crc32c"], 16) for j in order], dtype=np.uint64)
+    assert (r["check"] == want).all()
+
+
+def test_device_api_reports_small_output_region():
+    from brotli_amd.device import DeviceBatch
+    import torch
+    meta, distinct = H.packed_streams("cfg2_streams")
+    batch = DeviceBatch(distinct[:4], [65536, 1000, 65536, 65472])
+    batch.decode(check=0, lanes=64)
+    torch.cuda.synchronize()
+    r = batch.records()
+    assert list(r["rc"]) == [0, 5, 0, 5]
+    assert r["check"][1] == 65536 and r["got"][1] == 0
+
+
+def test_reference_harnesses_linked_against_the_drop_in():
+    # BASELINE config 1: the reference's own juxt.c/deb.c, compiled unmodified in the build
+    # container and linked against libyeast_mi355x.so (oracle/Makefile `dropin`)
+    juxt = os.path.join(H.ROOT, "oracle", "_ref", "juxt_dropin")
+    if not os.path.exists(juxt):
+        pytest.skip("drop-in harness binaries were not built")
+    files = [os.path.join(H.GOLD, "testdata", f) for f in sorted(os.listdir(os.path.join(H.GOLD, "testdata")))
+             if f.endswith(".compressed")]
+    p = subprocess.run([juxt, "-v"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0
+    assert b"yeast() returned" not in p.stderr, p.stderr[-400:]
+    assert p.stderr.count(b":\n") == 17
