@@ -29,58 +29,102 @@
 
 #define DEV __device__ __forceinline__
 #define NOINL __device__ __noinline__
+#ifndef YS_MIN_WAVES
+#define YS_MIN_WAVES 4
+#endif
 
-__constant__ u8 c_ctx_lut[768];  /* lut0 | lut1 | lut2 of yeast.c:700-740, filled by the host */
-__constant__ u32 c_len_tab[48];  /* insert (0..23) and copy (24..47) length codes: base | extra << 16 */
+__constant__ u8 c_ctx_lut[768]; /* lut0 | lut1 | lut2 of yeast.c:700-740, filled by the host */
+__constant__ u64 c_cmd_tab[704]; /* per insert-and-copy symbol: insert base | extra << 16 | copy base << 24 |
+                                    copy extra << 40  (insert_length()/copy_length(), yeast.c:652-693) */
+__constant__ u32 c_dict_tab[32]; /* per word length: DOFFSET | NDBITS << 24 (yeast.c:911-919) */
 
 /* LDS image shared by the groups of a block */
 struct Shared {
+    u64 cmd[704];
     u8 lut[768];
-    u32 len_tab[48];
+    u32 dict[32];
 };
+
+/* every access below is to global memory: say so, or pointers that travelled through an
+   out-of-line call are treated as generic and cost flat_* instructions */
+#define GAS __attribute__((address_space(1)))
+DEV u32 gld8(const void *p) { return *(const GAS u8 *)p; }
+DEV u32 gld16(const void *p) { return *(const GAS u16 *)p; }
+DEV u32 gld32(const void *p) { return *(const GAS u32 *)p; }
+DEV u64 gld64u(const void *p) /* unaligned */
+{
+    typedef u64 __attribute__((aligned(1))) u64u;
+    return *(const GAS u64u *)p;
+}
+DEV void gst8(void *p, u32 v) { *(GAS u8 *)p = (u8)v; }
+DEV void gst16(void *p, u32 v) { *(GAS u16 *)p = (u16)v; }
+DEV void gst32(void *p, u32 v) { *(GAS u32 *)p = v; }
+DEV void gst64(void *p, u64 v) { *(GAS u64 *)p = v; }
+DEV void gst64u(void *p, u64 v)
+{
+    typedef u64 __attribute__((aligned(1))) u64u;
+    *(GAS u64u *)p = v;
+}
 
 /* ------------------------------------------------------------- bit reader */
 
 struct Rd {
     const u32 *p; /* 4-byte aligned base at or before the current seek point */
-    u32 idx;      /* dword index of the next prefetch */
+    u32 idx;      /* dword index (from p) of the word held in nxt */
     u32 nxt;      /* prefetched dword */
     u64 w;        /* window, next bit at bit 0 */
-    u32 have;     /* bits in w (may extend past the end of the stream) */
-    u64 pos;      /* bits consumed since the start of the stream */
-    u64 nbits;    /* 8 * stream length; forced to 0 once rc is set */
+    u32 have;     /* valid bits in w */
+    u32 rem;      /* valid bits of the stream not yet moved into w */
+    u32 total;    /* 8 * stream length */
     u32 rc;       /* sticky status */
+    u32 fpos;     /* bits consumed when rc was set */
     u32 dry;      /* the reader ran out of input: the reference had pulled every byte */
 };
 
+DEV u32 rd_pos(const Rd &r) { return r.rc ? r.fpos : r.total - r.rem - r.have; }
+
 DEV void rd_fail(Rd &r, u32 code)
 {
-    if (!r.rc)
+    if (!r.rc) {
+        r.fpos = r.total - r.rem - r.have;
         r.rc = code;
-    r.nbits = 0;
+    }
+    r.have = 0;
+    r.rem = 0;
 }
 
-DEV void rd_seek(Rd &r, const u8 *src, u64 bitpos)
+DEV void rd_seek(Rd &r, const u8 *src, u32 bitpos)
 {
     const u8 *at = src + (bitpos >> 3);
     u32 mis = (u32)((uintptr_t)at & 3);
     r.p = (const u32 *)(at - mis);
-    u32 sh = mis * 8 + (u32)(bitpos & 7);
-    u64 lo = r.p[0], hi = r.p[1];
+    u32 sh = mis * 8 + (bitpos & 7);
+    u64 lo = gld32(r.p), hi = gld32(r.p + 1);
     r.w = (lo | (hi << 32)) >> sh;
-    r.have = 64 - sh;
-    r.nxt = r.p[2];
-    r.idx = 3;
-    r.pos = bitpos;
+    u32 left = r.total - bitpos;
+    r.have = 64 - sh < left ? 64 - sh : left;
+    r.rem = left - r.have;
+    r.nxt = gld32(r.p + 2);
+    r.idx = 2;
 }
 
 DEV void rd_refill(Rd &r)
 {
     if (r.have <= 32) {
         r.w |= (u64)r.nxt << r.have;
-        r.have += 32;
-        r.nxt = r.p[r.idx++];
+        u32 add = r.rem < 32 ? r.rem : 32;
+        r.have += add;
+        r.rem -= add;
+        r.idx += add ? 1 : 0; /* never runs more than two words past the end */
+        r.nxt = gld32(r.p + r.idx);
     }
+}
+
+DEV void rd_eof(Rd &r)
+{
+    if (!r.rc)
+        r.dry = 1;
+    rd_fail(r, YS_EOF);
 }
 
 /* bits(): yeast.c:163-179.  n <= 25.  On exhaustion the reference has pulled
@@ -88,26 +132,31 @@ DEV void rd_refill(Rd &r)
 DEV u32 take(Rd &r, u32 n)
 {
     rd_refill(r);
-    if (r.pos + n > r.nbits) {
-        if (!r.rc) {
-            r.rc = YS_EOF;
-            r.dry = 1;
-        }
-        r.nbits = 0;
+    if (n > r.have) {
+        rd_eof(r);
         n = 0;
     }
     u32 v = (u32)r.w & ((1u << n) - 1);
     r.w >>= n;
     r.have -= n;
-    r.pos += n;
     return v;
 }
 
-/* "s->left && s->bits": the rest of the current byte is not zero */
+/* "s->left && s->bits": the rest of the current byte is not zero.  Bits enter
+   the window in whole bytes, so the bits left in the current byte are have % 8. */
 DEV bool tail_nonzero(const Rd &r)
 {
-    u32 k = (u32)(r.pos & 7);
-    return k && ((u32)r.w & ((1u << (8 - k)) - 1));
+    u32 k = r.have & 7;
+    return k && ((u32)r.w & ((1u << k) - 1));
+}
+
+/* drop the rest of the current byte; returns the new bit position */
+DEV u32 rd_align(Rd &r)
+{
+    u32 k = r.have & 7;
+    r.w >>= k;
+    r.have -= k;
+    return r.total - r.rem - r.have;
 }
 
 /* -------------------------------------------------------------- LUT decode
@@ -122,23 +171,18 @@ DEV u32 dec_sym(Rd &r, const u16 *t)
 {
     rd_refill(r);
     u32 peek = (u32)r.w;
-    u32 e = t[peek & 255];
+    u32 e = gld16(t + (peek & 255));
     u32 l = e & 15;
     if (l > ROOT) {
-        e = t[(e >> 4) + ((peek >> ROOT) & ((1u << (l - ROOT)) - 1))];
+        e = gld16(t + (e >> 4) + ((peek >> ROOT) & ((1u << (l - ROOT)) - 1)));
         l = e & 15;
     }
-    if (r.pos + l > r.nbits) {
-        if (!r.rc) {
-            r.rc = YS_EOF;
-            r.dry = 1;
-        }
-        r.nbits = 0;
+    if (l > r.have) {
+        rd_eof(r);
         l = 0;
     }
     r.w >>= l;
     r.have -= l;
-    r.pos += l;
     return e >> 4;
 }
 
@@ -178,6 +222,7 @@ struct Hdr {
     u8 *ws;
     u32 arena_used, arena_size; /* bytes, relative to ws + YS_WS_ARENA */
     u32 tab;                    /* result: byte offset of the table from ws */
+    u32 sub, glog;              /* lane within the group, log2(lanes per group) */
 };
 
 /* Build the decode table of a complete canonical code (construct():
@@ -194,12 +239,12 @@ DEV void build_table(Hdr &h, const Cnt16 &count)
     }
     u16 *t = (u16 *)(h.ws + h.tab);
     const u16 *sorted = (const u16 *)(h.ws + YS_WS_SORT);
+    const u32 sub = h.sub, glog = h.glog;
 
     if (cnt_get(count, 0)) { /* one symbol, zero bits */
-        u32 e = (u32)sorted[0] << 4;
-        u64 e4 = (u64)e * 0x0001000100010001ull;
-        for (u32 i = 0; i < 64; i++)
-            ((u64 *)t)[i] = e4;
+        u64 e4 = (u64)(gld16(sorted) << 4) * 0x0001000100010001ull;
+        for (u32 i = sub; i < 64; i += 1u << glog)
+            gst64((u64 *)t + i, e4);
         h.arena_used += 512;
         return;
     }
@@ -212,21 +257,22 @@ DEV void build_table(Hdr &h, const Cnt16 &count)
         code <<= 1;
         u32 n = cnt_get(count, len);
         for (u32 k = 0; k < n; k++, si++, code++) {
-            u32 s = sorted[si];
+            u32 s = gld16(sorted + si);
             u32 rev = __builtin_bitreverse32(code) >> (32 - len); /* stream bit order */
             u32 e = (s << 4) | len;
             if (len <= ROOT) {
-                for (u32 i = rev; i < 256; i += 1u << len)
-                    t[i] = (u16)e;
+                /* the replicas of one code are spread over the lanes of the group */
+                for (u32 i = rev + (sub << len); i < 256; i += 1u << (len + glog))
+                    gst16(t + i, e);
             } else {
                 u32 key = rev & 255;
                 if (key != sub_key) { /* open the next sub-table */
                     sub_key = key;
                     sub_base = total;
                     u32 l2 = len;
-                    i64 room = (i64)1 << (l2 - ROOT);
+                    int room = 1 << (l2 - ROOT);
                     while (l2 < 15) {
-                        room -= cnt_get(left, l2);
+                        room -= (int)cnt_get(left, l2);
                         if (room <= 0)
                             break;
                         l2++;
@@ -238,10 +284,11 @@ DEV void build_table(Hdr &h, const Cnt16 &count)
                         rd_fail(h.r, YS_WORKSPACE);
                         return;
                     }
-                    t[key] = (u16)((sub_base << 4) | (ROOT + sub_bits));
+                    gst16(t + key, (sub_base << 4) | (ROOT + sub_bits));
                 }
-                for (u32 i = rev >> ROOT; i < (1u << sub_bits); i += 1u << (len - ROOT))
-                    t[sub_base + i] = (u16)e;
+                u32 sl = len - ROOT;
+                for (u32 i = (rev >> ROOT) + (sub << sl); i < (1u << sub_bits); i += 1u << (sl + glog))
+                    gst16(t + sub_base + i, e);
             }
             cnt_dec(left, len);
         }
@@ -294,7 +341,7 @@ NOINL Hdr read_code(Hdr h, u32 num)
             ORD(s2, s3);
         }
 #undef ORD
-        sorted[0] = (u16)s0; sorted[1] = (u16)s1; sorted[2] = (u16)s2; sorted[3] = (u16)s3;
+        gst16(sorted, s0); gst16(sorted + 1, s1); gst16(sorted + 2, s2); gst16(sorted + 3, s3);
         build_table(h, count);
         return h;
     }
@@ -316,15 +363,11 @@ NOINL Hdr read_code(Hdr h, u32 num)
         u32 pk = (u32)r.w & 15;
         u32 l = (u32)(FIX_LEN >> (pk * 4)) & 15;
         u32 s = (u32)(FIX_SYM >> (pk * 4)) & 15;
-        if (r.pos + l > r.nbits) {
-            if (!r.rc) {
-                r.rc = YS_EOF;
-                r.dry = 1;
-            }
-            r.nbits = 0;
+        if (l > r.have) {
+            rd_eof(r);
             return h;
         }
-        r.w >>= l; r.have -= l; r.pos += l;
+        r.w >>= l; r.have -= l;
         u32 k = nsym < 12 ? (u32)(ORD_LO >> (nsym * 5)) & 31 : (u32)(ORD_HI >> ((nsym - 12) * 5)) & 31;
         nsym++;
         clen |= (u64)s << (k * 3);
@@ -369,11 +412,13 @@ NOINL Hdr read_code(Hdr h, u32 num)
     }
 
     /* ---- the code lengths themselves, yeast.c:464-518 ---- */
-    if (h.arena_used + 704 + 16 + YS_TAB_ENTRIES * 2 > h.arena_size) {
+    if (h.arena_used + 704 * 2 + 16 + YS_TAB_ENTRIES * 2 > h.arena_size) {
         rd_fail(r, YS_WORKSPACE);
         return h;
     }
-    u8 *lens = (u8 *)(h.ws + YS_WS_ARENA + h.arena_used); /* scratch where the table will go */
+    /* coded symbols as (length << 12 | symbol), in symbol order; scratch above the table's place */
+    u16 *nz = (u16 *)(h.ws + YS_WS_ARENA + h.arena_used + YS_TAB_ENTRIES * 2);
+    u32 nnz = 0;
     int left = 1 << 15;
     u32 prev = 8, rep = 0, zeros = 0, n;
     nsym = 0;
@@ -384,23 +429,20 @@ NOINL Hdr read_code(Hdr h, u32 num)
         u64 x = q == 0 ? q0 : q == 1 ? q1 : q == 2 ? q2 : q3;
         u32 e = (u32)(x >> ((pk & 7) * 8)) & 255;
         u32 l = e & 7;
-        if (r.pos + l > r.nbits) {
-            if (!r.rc) {
-                r.rc = YS_EOF;
-                r.dry = 1;
-            }
-            r.nbits = 0;
+        if (l > r.have) {
+            rd_eof(r);
             return h;
         }
-        r.w >>= l; r.have -= l; r.pos += l;
+        r.w >>= l; r.have -= l;
         u32 len = e >> 3;
         if (len < 16) {
-            lens[nsym++] = (u8)len;
             if (len) {
+                gst16(nz + nnz++, (len << 12) | nsym);
                 left -= (1 << 15) >> len;
                 prev = len;
                 cnt_add(count, len, 1);
             }
+            nsym++;
             rep = 0;
             zeros = 0;
         } else if (len == 16) {
@@ -418,7 +460,7 @@ NOINL Hdr read_code(Hdr h, u32 num)
                 break;
             cnt_add(count, prev, n);
             for (u32 k = 0; k < n; k++)
-                lens[nsym++] = (u8)prev;
+                gst16(nz + nnz++, (prev << 12) | nsym++);
             zeros = 0;
         } else {
             n = zeros;
@@ -430,8 +472,7 @@ NOINL Hdr read_code(Hdr h, u32 num)
                 rd_fail(r, YS_INVALID); /* too many repeats :508 */
                 return h;
             }
-            for (u32 k = 0; k < n; k++)
-                lens[nsym++] = 0;
+            nsym += n;
             rep = 0;
         }
     } while (left > 0 && nsym < num);
@@ -451,12 +492,11 @@ NOINL Hdr read_code(Hdr h, u32 num)
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (u32 s = 0; s < nsym; s++) {
-        u32 l = lens[s];
-        if (l) {
-            sorted[cnt_get(offs, l)] = (u16)s;
-            cnt_add(offs, l, 1);
-        }
+    for (u32 i = 0; i < nnz; i++) {
+        u32 e = gld16(nz + i);
+        u32 l = e >> 12;
+        gst16(sorted + cnt_get(offs, l), e & 0xfff);
+        cnt_add(offs, l, 1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     build_table(h, count);
@@ -507,7 +547,7 @@ NOINL Hdr read_context_map(Hdr h, u8 *map, u32 len, u32 trees)
         if (r.rc)
             return h;
         if (s == 0)
-            map[n++] = 0;
+            gst8(map + n++, 0);
         else if (s <= rlemax) {
             u32 z = (1u << s) + take(r, s);
             if (r.rc)
@@ -517,27 +557,27 @@ NOINL Hdr read_context_map(Hdr h, u8 *map, u32 len, u32 trees)
                 return h;
             }
             for (u32 k = 0; k < z; k++)
-                map[n++] = 0;
+                gst8(map + n++, 0);
         } else
-            map[n++] = (u8)(s - rlemax);
+            gst8(map + n++, s - rlemax);
     } while (n < len);
     if (take(r, 1)) { /* inverse move-to-front :629-646 */
         u8 *tab = h.ws + YS_WS_MTF;
         for (u32 k = 0; k < trees; k++)
-            tab[k] = (u8)k;
+            gst8(tab + k, k);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (n = 0; n < len; n++) {
-            u32 s = map[n];
+            u32 s = gld8(map + n);
             if (s >= trees)
                 s = 0; /* unreachable for a valid map; keeps the list index in range */
             if (s) {
-                u8 front = tab[s];
+                u32 front = gld8(tab + s);
                 for (u32 k = s; k; k--)
-                    tab[k] = tab[k - 1];
-                tab[0] = front;
-                map[n] = front;
+                    gst8(tab + k, gld8(tab + k - 1));
+                gst8(tab, front);
+                gst8(map + n, front);
             } else
-                map[n] = tab[0];
+                gst8(map + n, gld8(tab));
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -554,8 +594,9 @@ struct Blk { /* one block category: yeast.c:112-123 */
 struct Ctx {
     Rd r;
     const u8 *src;
-    u8 *out;
-    u64 got, cap;
+    u8 *out;  /* start of this stream's output region */
+    u8 *outp; /* next output byte: out + got */
+    u64 cap;
     u32 wsize;
     u32 r0, r1, r2, r3; /* last four distances, r0 most recent (ring[] yeast.c:126) */
     u32 postfix, direct;
@@ -563,7 +604,7 @@ struct Ctx {
     u32 lit_codes, dist_codes;
     u8 *ws;
     u32 arena_size;
-    u32 p1, p2, ctx_stale;
+    u32 p1, p2;
     u32 nmeta;
     u64 need; /* output bytes required when rc == YS_CAPACITY */
     const u8 *dict, *xf;
@@ -571,9 +612,10 @@ struct Ctx {
 };
 
 DEV const u16 *tab_at(const Ctx &c, u32 off) { return (const u16 *)(c.ws + off); }
+DEV u64 got_of(const Ctx &c) { return (u64)(c.outp - c.out); }
 
 /* one category's NBLTYPES header: yeast.c:1079-1118 */
-DEV void read_block_header(Ctx &c, Hdr &h, Blk &k)
+DEV void read_block_header(Hdr &h, Blk &k)
 {
     k.prev = 1;
     k.type = 0;
@@ -628,90 +670,123 @@ DEV u32 group_min(u32 v)
 }
 
 /* LZ77 copy of n bytes from distance d (yeast.c:1285-1293): byte-serial
-   semantics, so an overlapping copy repeats its first d bytes. */
+   semantics, so an overlapping copy repeats its first d bytes.  ctx: also
+   fetch the last two bytes of the copy (from its source) for the literal
+   context of the next command. */
 template <int G, bool CMP>
-DEV void emit_copy(Ctx &c, u32 n, u64 d, u32 sub)
+DEV void emit_copy(Ctx &c, u32 n, u32 d, u32 sub, bool ctx)
 {
-    u8 *dst = c.out + c.got;
+    u8 *dst = c.outp;
     const u8 *from = dst - d;
     if (CMP) {
         /* every byte is compared with the expected data itself d bytes back */
         u32 bad = 0xffffffffu;
         for (u32 i = sub; i < n; i += G)
-            if (dst[i] != from[i] && i < bad)
+            if (gld8(dst + i) != gld8(from + i) && i < bad)
                 bad = i;
         bad = group_min<G>(bad);
         if (bad != 0xffffffffu) {
-            c.got += bad;
+            c.outp += bad;
             rd_fail(c.r, YS_MISMATCH);
             return;
         }
-        c.got += n;
+        c.outp += n;
+        if (ctx) {
+            c.p1 = gld8(c.outp - 1);
+            c.p2 = gld8(c.outp - 2);
+        }
         return;
     }
-    if (d >= n) { /* disjoint: 8-byte units spread over the lanes, then the tail */
+    if (d >= n || (G == 1 && d >= 8)) {
+        /* disjoint (or, for a single lane, far enough apart to go in order):
+           8-byte units spread over the lanes, then the tail */
+        u32 i1 = n - 1, i2 = n - 2;
+        if (G == 1 && d < n) {
+            i1 %= d;
+            i2 %= d;
+        }
+        if (ctx) {
+            c.p1 = gld8(from + i1);
+            c.p2 = gld8(from + i2);
+        }
         u32 n8 = n >> 3;
-        for (u32 j = sub; j < n8; j += G) {
-            u64 v;
-            __builtin_memcpy(&v, from + 8 * j, 8);
-            __builtin_memcpy(dst + 8 * j, &v, 8);
-        }
+        for (u32 j = sub; j < n8; j += G)
+            gst64u(dst + 8 * j, gld64u(from + 8 * j));
         for (u32 i = (n8 << 3) + sub; i < n; i += G)
-            dst[i] = from[i];
-    } else if (G == 1 && d >= 8) {
-        u32 i = 0;
-        for (; i + 8 <= n; i += 8) {
-            u64 v;
-            __builtin_memcpy(&v, from + i, 8);
-            __builtin_memcpy(dst + i, &v, 8);
-        }
-        for (; i < n; i++)
-            dst[i] = from[i];
+            gst8(dst + i, gld8(from + i));
     } else { /* overlapping: byte i repeats byte i mod d of the source */
-        u32 dd = (u32)d;
-        u32 m = sub % dd, step = G % dd;
+        if (ctx) {
+            c.p1 = gld8(from + (n - 1) % d);
+            c.p2 = gld8(from + (n - 2) % d);
+        }
+        u32 m = sub % d, step = G % d;
         for (u32 i = sub; i < n; i += G) {
-            dst[i] = from[m];
+            gst8(dst + i, gld8(from + m));
             m += step;
-            if (m >= dd)
-                m -= dd;
+            if (m >= d)
+                m -= d;
         }
     }
-    c.got += n;
+    c.outp += n;
+}
+
+/* The same copy for the flat loop when there is slack behind the destination:
+   whole 8-byte units only; up to 7 bytes beyond the end are scribbled on and
+   overwritten by whatever is decoded next (never read before that). */
+template <int G>
+DEV void emit_copy_wild(Ctx &c, u32 n, u32 d, u32 sub, bool ctx)
+{
+    u8 *dst = c.outp;
+    const u8 *from = dst - d;
+    if (d >= n || (G == 1 && d >= 8)) {
+        if (ctx) {
+            if (d >= n) {
+                u32 v = gld8(from + n - 2) | (gld8(from + n - 1) << 8);
+                c.p2 = v & 255;
+                c.p1 = v >> 8;
+            } else {
+                c.p1 = gld8(from + (n - 1) % d);
+                c.p2 = gld8(from + (n - 2) % d);
+            }
+        }
+        for (u32 j = sub * 8; j < n; j += G * 8)
+            gst64u(dst + j, gld64u(from + j));
+    } else {
+        if (ctx) {
+            c.p1 = gld8(from + (n - 1) % d);
+            c.p2 = gld8(from + (n - 2) % d);
+        }
+        u32 m = sub % d, step = G % d;
+        for (u32 i = sub; i < n; i += G) {
+            gst8(dst + i, gld8(from + m));
+            m += step;
+            if (m >= d)
+                m -= d;
+        }
+    }
+    c.outp += n;
 }
 
 /* dict_word(): yeast.c:908-949 with the elementary transforms :799-879.
    Byte k of the result is computed independently by whichever lane owns it. */
 template <int G, bool CMP>
-DEV void emit_dict(Ctx &c, u32 copy, u64 id, u32 &mlen, u32 sub)
+DEV void emit_dict(Ctx &c, u32 copy, u64 id, u32 &mlen, u32 sub, bool ctx)
 {
     if (copy > 24 || copy < 4) {
         rd_fail(c.r, YS_INVALID); /* :921-924 */
         return;
     }
-    /* NDBITS (yeast.c:916-919), 4 bits per length */
-    const u64 NDB_LO = (10ull << 16) | (10ull << 20) | (11ull << 24) | (11ull << 28) | (10ull << 32) |
-                       (10ull << 36) | (10ull << 40) | (10ull << 44) | (10ull << 48) | (9ull << 52) |
-                       (9ull << 56) | (8ull << 60);                /* lengths 4..15 at bits 4*len */
-    const u64 NDB_HI = 7ull | (7ull << 4) | (8ull << 8) | (7ull << 12) | (7ull << 16) | (6ull << 20) |
-                       (6ull << 24) | (5ull << 28) | (5ull << 32); /* lengths 16..24 */
-    u32 nd = copy < 16 ? (u32)(NDB_LO >> (copy * 4)) & 15 : (u32)(NDB_HI >> ((copy - 16) * 4)) & 15;
+    u32 de = c.sh->dict[copy];
+    u32 nd = de >> 24;
     u64 xform = id >> nd;
     if (xform >= 121) {
         rd_fail(c.r, YS_INVALID); /* :929-930 */
         return;
     }
     u32 index = (u32)id & ((1u << nd) - 1);
-    /* DOFFSET[len] (yeast.c:911-915) = sum over l < len of l << NDBITS[l] */
-    u32 doff = 0;
-    for (u32 l = 4; l < copy; l++) {
-        u32 b = l < 16 ? (u32)(NDB_LO >> (l * 4)) & 15 : (u32)(NDB_HI >> ((l - 16) * 4)) & 15;
-        doff += l << b;
-    }
-    const u8 *w = c.dict + doff + index * copy;
+    const u8 *w = c.dict + (de & 0xffffff) + index * copy;
     const u8 *t = c.xf + 20 * (u32)xform;
-    u32 hdr;
-    __builtin_memcpy(&hdr, t, 4);
+    u32 hdr = gld32(t);
     u32 op = hdr & 255, omit = (hdr >> 8) & 255, plen = (hdr >> 16) & 255, slen = hdr >> 24;
     u32 wlen = copy, wskip = 0;
     if (op == 3) { /* omit first */
@@ -729,7 +804,7 @@ DEV void emit_dict(Ctx &c, u32 copy, u64 id, u32 &mlen, u32 sub)
     if (op == 1 || op == 2) {
         u32 j = 0;
         do {
-            u32 ch = w[j];
+            u32 ch = gld8(w + j);
             if (ch < 192) {
                 if (ch >= 97 && ch <= 122)
                     x32 |= 1u << j;
@@ -745,23 +820,27 @@ DEV void emit_dict(Ctx &c, u32 copy, u64 id, u32 &mlen, u32 sub)
             }
         } while (op == 2 && j < copy);
     }
-    u8 *dst = c.out + c.got;
-    u32 bad = 0;
-    for (u32 k = sub; k < total; k += G) {
+    auto byte_at = [&](u32 k) -> u32 {
         u32 v;
         if (k < plen)
-            v = t[4 + k];
+            v = gld8(t + 4 + k);
         else if (k < plen + wlen) {
             u32 j = k - plen + wskip;
-            v = w[j];
+            v = gld8(w + j);
             v ^= ((x32 >> j) & 1) << 5;
             v ^= ((x5 >> j) & 1) * 5;
         } else
-            v = t[12 + k - plen - wlen];
+            v = gld8(t + 12 + k - plen - wlen);
+        return v;
+    };
+    u8 *dst = c.outp;
+    u32 bad = 0;
+    for (u32 k = sub; k < total; k += G) {
+        u32 v = byte_at(k);
         if (CMP)
-            bad |= dst[k] != v;
+            bad |= gld8(dst + k) != v;
         else
-            dst[k] = (u8)v;
+            gst8(dst + k, v);
     }
     if (CMP) {
         if (__any(bad)) { /* whole-wave vote: CMP is only instantiated with G == 64 */
@@ -769,7 +848,16 @@ DEV void emit_dict(Ctx &c, u32 copy, u64 id, u32 &mlen, u32 sub)
             return;
         }
     }
-    c.got += total;
+    if (ctx) {
+        if (total >= 2) {
+            c.p1 = byte_at(total - 1);
+            c.p2 = byte_at(total - 2);
+        } else if (total == 1) {
+            c.p2 = c.p1;
+            c.p1 = byte_at(0);
+        }
+    }
+    c.outp += total;
     mlen -= total;
 }
 
@@ -777,26 +865,26 @@ DEV void emit_dict(Ctx &c, u32 copy, u64 id, u32 &mlen, u32 sub)
 template <int G, bool CMP>
 DEV void emit_raw(Ctx &c, const u8 *from, u32 n, u32 sub)
 {
-    u8 *dst = c.out + c.got;
+    u8 *dst = c.outp;
     if (CMP) {
         u32 bad = 0;
         for (u32 i = sub; i < n; i += G)
-            bad |= dst[i] != from[i];
+            bad |= gld8(dst + i) != gld8(from + i);
         if (__any(bad)) {
             rd_fail(c.r, YS_MISMATCH); /* memcmp over the block: got unchanged :1063 */
             return;
         }
     } else {
         u32 n8 = n >> 3;
-        for (u32 j = sub; j < n8; j += G) {
-            u64 v;
-            __builtin_memcpy(&v, from + 8 * j, 8);
-            __builtin_memcpy(dst + 8 * j, &v, 8);
-        }
+        for (u32 j = sub; j < n8; j += G)
+            gst64u(dst + 8 * j, gld64u(from + 8 * j));
         for (u32 i = (n8 << 3) + sub; i < n; i += G)
-            dst[i] = from[i];
+            gst8(dst + i, gld8(from + i));
     }
-    c.got += n;
+    c.outp += n;
+    /* literal context for what follows: the last two bytes of the block (n >= 1) */
+    c.p2 = n >= 2 ? gld8(from + n - 2) : c.p1;
+    c.p1 = gld8(from + n - 1);
 }
 
 /* the bytes a group has just written become visible to its own later loads */
@@ -805,7 +893,7 @@ DEV void group_sync_mem() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"
 /* ------------------------------------------------------------- meta-block */
 
 /* metablock(): yeast.c:971-1308.  Returns ISLAST. */
-template <int G, bool CMP>
+template <int G, bool CMP, bool FLAT>
 DEV u32 metablock(Ctx &c, u32 sub)
 {
     Rd &r = c.r;
@@ -831,13 +919,12 @@ DEV u32 metablock(Ctx &c, u32 sub)
             rd_fail(r, YS_INVALID);
             return 1;
         }
-        u64 pos = (r.pos + 7) & ~(u64)7;
-        r.pos = pos;
-        if ((u64)skip * 8 > r.nbits - pos) {
+        u32 pos = rd_align(r);
+        if (skip > ((r.total - pos) >> 3)) {
             rd_fail(r, YS_EOF); /* :1025, nothing more consumed */
             return 1;
         }
-        rd_seek(r, c.src, pos + (u64)skip * 8);
+        rd_seek(r, c.src, pos + skip * 8);
         return last;
     }
     u32 mlen = 1 + take(r, 16);
@@ -848,8 +935,8 @@ DEV u32 metablock(Ctx &c, u32 sub)
     }
     if (r.rc)
         return 1;
-    if (c.got + mlen > c.cap) { /* :1040-1047 */
-        c.need = c.got + mlen;
+    if (got_of(c) + mlen > c.cap) { /* :1040-1047 */
+        c.need = got_of(c) + mlen;
         rd_fail(r, CMP ? YS_MISMATCH : YS_CAPACITY);
         return 1;
     }
@@ -858,17 +945,15 @@ DEV u32 metablock(Ctx &c, u32 sub)
             rd_fail(r, YS_INVALID);
             return 1;
         }
-        u64 pos = (r.pos + 7) & ~(u64)7;
-        r.pos = pos;
-        if ((u64)mlen * 8 > r.nbits - pos) {
+        u32 pos = rd_align(r);
+        if (mlen > ((r.total - pos) >> 3)) {
             rd_fail(r, YS_EOF); /* :1059 */
             return 1;
         }
         emit_raw<G, CMP>(c, c.src + (pos >> 3), mlen, sub);
         if (r.rc)
             return 1;
-        rd_seek(r, c.src, pos + (u64)mlen * 8);
-        c.ctx_stale = 1;
+        rd_seek(r, c.src, pos + mlen * 8);
         return last;
     }
     if (r.rc)
@@ -881,15 +966,17 @@ DEV u32 metablock(Ctx &c, u32 sub)
     h.arena_used = 0;
     h.arena_size = c.arena_size;
     h.tab = YS_WS_ARENA;
-    read_block_header(c, h, c.L);
-    read_block_header(c, h, c.I);
-    read_block_header(c, h, c.D);
+    h.sub = sub;
+    h.glog = 31 - __builtin_clz((u32)G);
+    read_block_header(h, c.L);
+    read_block_header(h, c.I);
+    read_block_header(h, c.D);
     c.postfix = take(h.r, 2);
     c.direct = take(h.r, 4) << c.postfix;
     u32 dists = 16 + c.direct + (48u << c.postfix);
     u8 *mode = c.ws + YS_WS_MODE;
     for (n = 0; n < c.L.num; n++)
-        mode[n] = (u8)take(h.r, 2);
+        gst8(mode + n, take(h.r, 2));
     c.lit_codes = read_count256(h.r);
     /* literal context map (u8 per entry) and literal table map (u32 per entry) */
     u32 nmap = c.lit_codes > 1 ? (c.L.num << 6) : 0;
@@ -914,165 +1001,294 @@ DEV u32 metablock(Ctx &c, u32 sub)
     u32 *itab = (u32 *)(c.ws + YS_WS_ITAB), *dtab = (u32 *)(c.ws + YS_WS_DTAB);
     for (n = 0; n < c.lit_codes && !h.r.rc; n++) {
         h = read_code(h, 256);
-        ldir[n] = h.tab;
+        gst32(ldir + n, h.tab);
     }
     for (n = 0; n < c.I.num && !h.r.rc; n++) {
         h = read_code(h, 704);
-        itab[n] = h.tab;
+        gst32(itab + n, h.tab);
     }
     for (n = 0; n < c.dist_codes && !h.r.rc; n++) {
         h = read_code(h, dists);
-        ddir[n] = h.tab;
+        gst32(ddir + n, h.tab);
     }
     r = h.r;
     if (r.rc)
         return 1;
     group_sync_mem();
-    /* resolve the context maps to table offsets once */
-    u32 tL0 = ldir[0], tD0 = ddir[0];
-    for (n = 0; n < nmap; n++)
-        lit_tab[n] = ldir[lit_map[n]];
+    /* resolve the context maps to table offsets once, the entries spread over the lanes */
+    const u16 *tL0 = tab_at(c, gld32(ldir)), *tD0 = tab_at(c, gld32(ddir));
+    for (n = sub; n < nmap; n += G)
+        gst32(lit_tab + n, gld32(ldir + gld8(lit_map + n)));
     if (c.dist_codes > 1)
-        for (n = 0; n < (c.D.num << 2); n++)
-            dtab[n] = ddir[dist_map[n]];
+        for (n = sub; n < (c.D.num << 2); n += G)
+            gst32(dtab + n, gld32(ddir + gld8(dist_map + n)));
     group_sync_mem();
-    const u16 *tI = tab_at(c, itab[0]);
-    u32 cur_mode = mode[0];
-    const u32 *len_tab = c.sh->len_tab;
+    const u16 *tI = tab_at(c, gld32(itab));
+    u32 cur_mode = gld8(mode);
+    const bool ctx = c.lit_codes > 1;
+    const u64 *cmd_tab = c.sh->cmd;
 
-    /* ---- command loop: yeast.c:1166-1295 ---- */
-    do {
-        if (c.I.num > 1) {
-            if (c.I.left == 0) {
-                switch_block(c, c.I);
-                tI = tab_at(c, itab[c.I.type]);
+    if (!FLAT) {
+        /* ---- command loop: yeast.c:1166-1295 ---- */
+        do {
+            if (c.I.num > 1) {
+                if (c.I.left == 0) {
+                    switch_block(c, c.I);
+                    tI = tab_at(c, gld32(itab + c.I.type));
+                }
+                c.I.left--;
             }
-            c.I.left--;
-        }
-        u32 cmd = dec_sym(r, tI);
-        /* cell -> insert/copy code offsets, map[] of yeast.c:655 and :678, 5 bits a cell */
-        const u64 ICELL = 0ull | (0ull << 5) | (0ull << 10) | (0ull << 15) | (8ull << 20) | (8ull << 25) |
-                          (0ull << 30) | (16ull << 35) | (8ull << 40) | (16ull << 45) | (16ull << 50);
-        const u64 CCELL = 0ull | (8ull << 5) | (0ull << 10) | (8ull << 15) | (0ull << 20) | (8ull << 25) |
-                          (16ull << 30) | (0ull << 35) | (16ull << 40) | (8ull << 45) | (16ull << 50);
-        u32 cell = (cmd >> 6) & 15;
-        u32 ie = len_tab[((u32)(ICELL >> (cell * 5)) & 31) + ((cmd >> 3) & 7)];
-        u32 ce = len_tab[24 + ((u32)(CCELL >> (cell * 5)) & 31) + (cmd & 7)];
-        u32 insert = (ie & 0xffff) + take(r, ie >> 16);
-        u32 copy = (ce & 0xffff) + take(r, ce >> 16);
-        if (r.rc)
-            break;
-        if (insert > mlen) {
-            rd_fail(r, YS_INVALID); /* :1189 */
-            break;
-        }
-        mlen -= insert;
-        if (insert) {
-            if (c.ctx_stale && c.lit_codes > 1) {
-                group_sync_mem();
-                c.p1 = c.got ? c.out[c.got - 1] : 0;
-                c.p2 = c.got > 1 ? c.out[c.got - 2] : 0;
+            u32 cmd = dec_sym(r, tI);
+            u64 ce = cmd_tab[cmd < 704 ? cmd : 0];
+            u32 insert = ((u32)ce & 0xffff) + take(r, ((u32)ce >> 16) & 0xff);
+            u32 copy = ((u32)(ce >> 24) & 0xffff) + take(r, (u32)(ce >> 40));
+            if (r.rc)
+                break;
+            if (insert > mlen) {
+                rd_fail(r, YS_INVALID); /* :1189 */
+                break;
             }
-            c.ctx_stale = 0;
-            do {
+            mlen -= insert;
+            if (insert) {
+                do {
+                    if (c.L.num > 1) {
+                        if (c.L.left == 0) {
+                            switch_block(c, c.L);
+                            cur_mode = gld8(mode + c.L.type);
+                        }
+                        c.L.left--;
+                    }
+                    const u16 *tl = tL0;
+                    if (ctx)
+                        tl = tab_at(c, gld32(lit_tab + (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode)));
+                    u32 s = dec_sym(r, tl);
+                    if (r.rc)
+                        break;
+                    if (CMP) {
+                        u32 e = gld8(c.outp);
+                        c.outp++; /* yeast.c:1217: got advances before the compare throws */
+                        if (e != s) {
+                            rd_fail(r, YS_MISMATCH);
+                            break;
+                        }
+                    } else {
+                        gst8(c.outp, s);
+                        c.outp++;
+                    }
+                    c.p2 = c.p1;
+                    c.p1 = s;
+                } while (--insert);
+                if (r.rc)
+                    break;
+            }
+            if (mlen == 0)
+                break;
+
+            u64 got = got_of(c);
+            u32 max = got > c.wsize ? c.wsize : (u32)got;
+            i64 dist;
+            if (cmd < 128)
+                dist = c.r0;
+            else {
+                if (c.D.num > 1) {
+                    if (c.D.left == 0)
+                        switch_block(c, c.D);
+                    c.D.left--;
+                }
+                const u16 *td = tD0;
+                if (c.dist_codes > 1)
+                    td = tab_at(c, gld32(dtab + (c.D.type << 2) + (copy > 4 ? 3 : copy - 2)));
+                u32 ds = dec_sym(r, td);
+                /* distance(): yeast.c:761-789 */
+                if (ds < 16) {
+                    u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
+                    u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
+                    int dl = 0;
+                    if (ds >= 4) {
+                        u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
+                        dl = (int)(k >> 1) + 1;
+                        if (!(k & 1))
+                            dl = -dl;
+                    }
+                    dist = (i64)rv + dl;
+                } else if (ds < 16 + c.direct)
+                    dist = ds - 15;
+                else {
+                    u32 nn = ds - c.direct - 16;
+                    u32 x = 1 + (nn >> (c.postfix + 1));
+                    if (x > 25)
+                        x = 25; /* only after a read failure */
+                    u64 off = ((u64)(2 + ((nn >> c.postfix) & 1)) << x) - 4;
+                    dist = (i64)(((off + take(r, x)) << c.postfix) + (nn & ((1u << c.postfix) - 1)) + c.direct + 1);
+                }
+                if (r.rc)
+                    break;
+                if (ds && dist > 0 && dist <= (i64)max) {
+                    c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
+                }
+            }
+            if (dist <= 0) {
+                rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
+                break;
+            }
+            if (dist > (i64)max) {
+                emit_dict<G, CMP>(c, copy, (u64)dist - max - 1, mlen, sub, ctx);
+            } else {
+                if (copy > mlen) {
+                    rd_fail(r, YS_INVALID); /* :1283 */
+                    break;
+                }
+                mlen -= copy;
+                emit_copy<G, CMP>(c, copy, (u32)dist, sub, ctx);
+            }
+        } while (mlen && !r.rc);
+    } else {
+        /* ---- the same command loop as a flat state machine: every trip decodes exactly
+           one prefix code symbol per stream (insert-and-copy, literal or distance), so the
+           streams that share a wavefront stay converged on the expensive part -- the table
+           lookup -- whatever mix of commands they are in.  yeast.c:1166-1295. ---- */
+        enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3 };
+        u32 st = ST_CMD;
+        u32 offI = gld32(itab), offL = (u32)((const u8 *)tL0 - c.ws), offD0 = (u32)((const u8 *)tD0 - c.ws);
+        u32 insert = 0, copy = 0, implicit = 0;
+        u8 *const out_end = c.out + c.cap;
+        while (st != ST_END) {
+            u32 off;
+            if (st == ST_CMD) {
+                if (c.I.num > 1) {
+                    if (c.I.left == 0) {
+                        switch_block(c, c.I);
+                        offI = gld32(itab + c.I.type);
+                    }
+                    c.I.left--;
+                }
+                off = offI;
+            } else if (st == ST_LIT) {
                 if (c.L.num > 1) {
                     if (c.L.left == 0) {
                         switch_block(c, c.L);
-                        cur_mode = mode[c.L.type];
+                        cur_mode = gld8(mode + c.L.type);
+                        if (ctx)
+                            offL = gld32(lit_tab + (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode));
                     }
                     c.L.left--;
                 }
-                u32 tl = tL0;
-                if (c.lit_codes > 1)
-                    tl = lit_tab[(c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode)];
-                u32 s = dec_sym(r, tab_at(c, tl));
+                off = offL;
+            } else {
+                if (c.D.num > 1) {
+                    if (c.D.left == 0)
+                        switch_block(c, c.D);
+                    c.D.left--;
+                }
+                off = offD0;
+                if (c.dist_codes > 1)
+                    off = gld32(dtab + (c.D.type << 2) + (copy > 4 ? 3 : copy - 2));
+            }
+            u32 sym = dec_sym(r, (const u16 *)(c.ws + off));
+            if (r.rc)
+                break;
+            bool do_copy = false;
+            i64 dist = 0;
+            if (st == ST_CMD) {
+                u64 ce = cmd_tab[sym < 704 ? sym : 0];
+                insert = ((u32)ce & 0xffff) + take(r, ((u32)ce >> 16) & 0xff);
+                copy = ((u32)(ce >> 24) & 0xffff) + take(r, (u32)(ce >> 40));
                 if (r.rc)
                     break;
-                if (CMP) {
-                    u32 e = c.out[c.got];
-                    c.got++; /* yeast.c:1217: got advances before the compare throws */
-                    if (e != s) {
-                        rd_fail(r, YS_MISMATCH);
+                if (insert > mlen) {
+                    rd_fail(r, YS_INVALID); /* :1189 */
+                    break;
+                }
+                mlen -= insert;
+                implicit = sym < 128;
+                if (insert)
+                    st = ST_LIT;
+                else if (implicit) {
+                    do_copy = true;
+                    dist = c.r0;
+                } else
+                    st = ST_DIST;
+            } else if (st == ST_LIT) {
+                gst8(c.outp, sym);
+                c.outp++;
+                c.p2 = c.p1;
+                c.p1 = sym;
+                if (--insert == 0) {
+                    if (mlen == 0)
+                        st = ST_END; /* the copy length is ignored :1227 */
+                    else if (implicit) {
+                        do_copy = true;
+                        dist = c.r0;
+                    } else
+                        st = ST_DIST;
+                }
+            } else { /* distance(): yeast.c:761-789 */
+                u64 got = got_of(c);
+                u32 max = got > c.wsize ? c.wsize : (u32)got;
+                u32 ds = sym;
+                if (ds < 16) {
+                    u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
+                    u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
+                    int dl = 0;
+                    if (ds >= 4) {
+                        u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
+                        dl = (int)(k >> 1) + 1;
+                        if (!(k & 1))
+                            dl = -dl;
+                    }
+                    dist = (i64)rv + dl;
+                } else if (ds < 16 + c.direct)
+                    dist = ds - 15;
+                else {
+                    u32 nn = ds - c.direct - 16;
+                    u32 x = 1 + (nn >> (c.postfix + 1));
+                    if (x > 25)
+                        x = 25; /* only after a read failure */
+                    u64 o2 = ((u64)(2 + ((nn >> c.postfix) & 1)) << x) - 4;
+                    dist = (i64)(((o2 + take(r, x)) << c.postfix) + (nn & ((1u << c.postfix) - 1)) + c.direct + 1);
+                }
+                if (r.rc)
+                    break;
+                if (ds && dist > 0 && dist <= (i64)max) {
+                    c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
+                }
+                do_copy = true;
+            }
+            if (do_copy) {
+                u64 got = got_of(c);
+                u32 max = got > c.wsize ? c.wsize : (u32)got;
+                if (dist <= 0) {
+                    rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
+                    break;
+                }
+                if (dist > (i64)max) {
+                    emit_dict<G, false>(c, copy, (u64)dist - max - 1, mlen, sub, ctx);
+                } else {
+                    if (copy > mlen) {
+                        rd_fail(r, YS_INVALID); /* :1283 */
                         break;
                     }
-                } else {
-                    c.out[c.got] = (u8)s;
-                    c.got++;
+                    mlen -= copy;
+                    if (c.outp + copy + 16 <= out_end)
+                        emit_copy_wild<G>(c, copy, (u32)dist, sub, ctx);
+                    else
+                        emit_copy<G, false>(c, copy, (u32)dist, sub, ctx);
                 }
-                c.p2 = c.p1;
-                c.p1 = s;
-            } while (--insert);
-            if (r.rc)
-                break;
-        }
-        if (mlen == 0)
-            break;
-
-        u64 max = c.got > c.wsize ? c.wsize : c.got;
-        i64 dist;
-        if (cmd < 128)
-            dist = c.r0;
-        else {
-            if (c.D.num > 1) {
-                if (c.D.left == 0)
-                    switch_block(c, c.D);
-                c.D.left--;
+                if (r.rc)
+                    break;
+                st = mlen ? ST_CMD : ST_END;
             }
-            u32 td = tD0;
-            if (c.dist_codes > 1)
-                td = dtab[(c.D.type << 2) + (copy > 4 ? 3 : copy - 2)];
-            u32 ds = dec_sym(r, tab_at(c, td));
-            /* distance(): yeast.c:761-789 */
-            if (ds < 16) {
-                u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
-                u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
-                int dl = 0;
-                if (ds >= 4) {
-                    u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
-                    dl = (int)(k >> 1) + 1;
-                    if (!(k & 1))
-                        dl = -dl;
-                }
-                dist = (i64)rv + dl;
-            } else if (ds < 16 + c.direct)
-                dist = ds - 15;
-            else {
-                u32 nn = ds - c.direct - 16;
-                u32 x = 1 + (nn >> (c.postfix + 1));
-                if (x > 25)
-                    x = 25; /* only after a read failure */
-                u64 off = ((u64)(2 + ((nn >> c.postfix) & 1)) << x) - 4;
-                dist = (i64)(((off + take(r, x)) << c.postfix) + (nn & ((1u << c.postfix) - 1)) + c.direct + 1);
-            }
-            if (r.rc)
-                break;
-            if (ds && dist > 0 && (u64)dist <= max) {
-                c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
-            }
+            if (st == ST_LIT && ctx)
+                offL = gld32(lit_tab + (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode));
         }
-        if (dist <= 0) {
-            rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
-            break;
-        }
-        if ((u64)dist > max) {
-            emit_dict<G, CMP>(c, copy, (u64)dist - max - 1, mlen, sub);
-        } else {
-            if (copy > mlen) {
-                rd_fail(r, YS_INVALID); /* :1283 */
-                break;
-            }
-            mlen -= copy;
-            emit_copy<G, CMP>(c, copy, (u64)dist, sub);
-        }
-        c.ctx_stale = 1;
-    } while (mlen && !r.rc);
+    }
     if (!r.rc && last && tail_nonzero(r))
         rd_fail(r, YS_INVALID); /* :1305 */
     return last;
 }
 
 /* yeast(): yeast.c:1353-1400 for one stream of the batch */
-template <int G, bool CMP>
+template <int G, bool CMP, bool FLAT>
 DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub)
 {
     Ctx c;
@@ -1080,16 +1296,16 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     u64 d0 = p.dst_off[job], d1 = p.dst_off[job + 1];
     c.src = p.src + s0;
     c.out = p.dst + d0;
+    c.outp = c.out;
     c.cap = d1 - d0;
-    c.got = 0;
     c.r.rc = YS_OK;
     c.r.dry = 0;
-    c.r.nbits = (s1 - s0) * 8;
+    c.r.fpos = 0;
+    c.r.total = (u32)(s1 - s0) * 8;
     c.r0 = 4; c.r1 = 11; c.r2 = 15; c.r3 = 16; /* :1327-1331, most recent first */
     c.ws = ws;
     c.arena_size = (u32)(p.ws_stride - YS_WS_ARENA);
     c.p1 = c.p2 = 0;
-    c.ctx_stale = 0;
     c.nmeta = 0;
     c.need = 0;
     c.dict = p.dict;
@@ -1097,6 +1313,8 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     c.sh = sh;
     c.L.num = c.I.num = c.D.num = 1;
     rd_seek(c.r, c.src, 0);
+    if (s1 - s0 >= (1u << 29))
+        rd_fail(c.r, YS_NOMEM); /* the bit cursor is 32 bits wide: streams of 512 MiB and more are refused */
 
     u32 wbits = 16;
     if (take(c.r, 1)) { /* WBITS :1372-1378 */
@@ -1112,7 +1330,7 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
         rd_fail(c.r, YS_INVALID);
     c.wsize = (1u << wbits) - 16;
     while (!c.r.rc) {
-        u32 last = metablock<G, CMP>(c, sub);
+        u32 last = metablock<G, CMP, FLAT>(c, sub);
         if (c.r.rc)
             break;
         c.nmeta++;
@@ -1123,9 +1341,9 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     ys_record rec;
     rec.rc = (int32_t)c.r.rc;
     rec.flags = wbits | ((c.nmeta > 0xffffff ? 0xffffffu : c.nmeta) << 8);
-    rec.got = c.got;
+    rec.got = got_of(c);
     /* bytes pulled: every byte when the bit reader ran dry, else ceil(bits/8) (yeast.c:1388) */
-    rec.used = c.r.dry ? (s1 - s0) : (c.r.pos + 7) >> 3;
+    rec.used = c.r.dry ? (s1 - s0) : (rd_pos(c.r) + 7) >> 3;
     rec.check = c.need;
     p.rec[job] = rec;
     if (c.r.rc == YS_WORKSPACE && !p.retry && sub == 0)
@@ -1133,13 +1351,15 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
 }
 
 template <int G, bool CMP>
-__global__ __launch_bounds__(256) void k_decode(ys_params p)
+__global__ __launch_bounds__(256, YS_MIN_WAVES) void k_decode(ys_params p)
 {
     __shared__ Shared sh;
+    for (u32 i = threadIdx.x; i < 704; i += blockDim.x)
+        sh.cmd[i] = c_cmd_tab[i];
     for (u32 i = threadIdx.x; i < 768; i += blockDim.x)
         sh.lut[i] = c_ctx_lut[i];
-    if (threadIdx.x < 48)
-        sh.len_tab[threadIdx.x] = c_len_tab[threadIdx.x];
+    if (threadIdx.x < 32)
+        sh.dict[threadIdx.x] = c_dict_tab[threadIdx.x];
     __syncthreads();
     u32 lane = threadIdx.x;
     u32 sub = lane & (G - 1);
@@ -1155,7 +1375,43 @@ __global__ __launch_bounds__(256) void k_decode(ys_params p)
             break;
         if (p.retry)
             job = p.retry_list[job];
-        decode_stream<G, CMP>(p, job, ws, &sh, sub);
+        decode_stream<G, CMP, false>(p, job, ws, &sh, sub);
+    }
+}
+
+/* Batch kernel: every group of a wavefront starts its stream at the same time, so header
+   parsing, the flat command loop and the record write-out run converged across the
+   64 / G streams of the wavefront; a wavefront takes the next 64 / G streams when all
+   of its groups are done. */
+template <int G>
+__global__ __launch_bounds__(256, 1) void k_decode_flat(ys_params p)
+{
+    __shared__ Shared sh;
+    for (u32 i = threadIdx.x; i < 704; i += blockDim.x)
+        sh.cmd[i] = c_cmd_tab[i];
+    for (u32 i = threadIdx.x; i < 768; i += blockDim.x)
+        sh.lut[i] = c_ctx_lut[i];
+    if (threadIdx.x < 32)
+        sh.dict[threadIdx.x] = c_dict_tab[threadIdx.x];
+    __syncthreads();
+    u32 lane = threadIdx.x;
+    u32 sub = lane & (G - 1);
+    u32 gid = (blockIdx.x * blockDim.x + lane) / G;
+    u8 *ws = p.ws + (u64)gid * p.ws_stride;
+    const u32 limit = p.retry ? *p.retry_count : p.n;
+    for (;;) {
+        u32 base = 0;
+        if ((lane & 63) == 0)
+            base = atomicAdd(p.counter, 64u / G);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= limit)
+            break;
+        u32 job = base + (lane & 63) / G;
+        if (job < limit) {
+            if (p.retry)
+                job = p.retry_list[job];
+            decode_stream<G, false, true>(p, job, ws, &sh, sub);
+        }
     }
 }
 
@@ -1163,25 +1419,43 @@ __global__ __launch_bounds__(256) void k_decode(ys_params p)
 
 extern "C" int ys_upload_constants(const u8 *lut768)
 {
-    /* insert_length()/copy_length() tables of yeast.c:658-665 and :681-688, from their structure:
-       each base is the previous base plus 1 << previous extra */
+    /* insert_length()/copy_length() tables of yeast.c:655-665 and :678-688, from their structure:
+       each base is the previous base plus 1 << previous extra; cell maps per symbol >> 6 */
     static const u8 ins_x[24] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 24};
     static const u8 cpy_x[24] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 24};
-    u32 tab[48];
+    static const u8 ins_cell[11] = {0, 0, 0, 0, 8, 8, 0, 16, 8, 16, 16};
+    static const u8 cpy_cell[11] = {0, 8, 0, 8, 0, 8, 16, 0, 16, 8, 16};
+    u32 ib[24], cb[24];
     u32 b = 0;
     for (int i = 0; i < 24; i++) {
-        tab[i] = b | ((u32)ins_x[i] << 16);
+        ib[i] = b;
         b += 1u << ins_x[i];
     }
     b = 2;
     for (int i = 0; i < 24; i++) {
-        tab[24 + i] = b | ((u32)cpy_x[i] << 16);
+        cb[i] = b;
         b += 1u << cpy_x[i];
+    }
+    static u64 cmd[704];
+    for (u32 s = 0; s < 704; s++) {
+        u32 ic = ins_cell[s >> 6] + ((s >> 3) & 7), cc = cpy_cell[s >> 6] + (s & 7);
+        cmd[s] = (u64)ib[ic] | ((u64)ins_x[ic] << 16) | ((u64)cb[cc] << 24) | ((u64)cpy_x[cc] << 40);
+    }
+    /* NDBITS (yeast.c:916-919); DOFFSET[len] = sum over l < len of l << NDBITS[l] (:911-915) */
+    static const u8 ndbits[25] = {0, 0, 0, 0, 10, 10, 11, 11, 10, 10, 10, 10, 10, 9, 9, 8, 7, 7, 8, 7, 7, 6, 6, 5, 5};
+    u32 dict[32] = {0};
+    u32 off = 0;
+    for (u32 l = 4; l <= 24; l++) {
+        dict[l] = off | ((u32)ndbits[l] << 24);
+        off += l << ndbits[l];
     }
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_ctx_lut), lut768, 768);
     if (e != hipSuccess)
         return (int)e;
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(c_len_tab), tab, sizeof(tab));
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_cmd_tab), cmd, sizeof(cmd));
+    if (e != hipSuccess)
+        return (int)e;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(c_dict_tab), dict, sizeof(dict));
 }
 
 template <int G, bool CMP>
@@ -1203,8 +1477,27 @@ extern "C" int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cm
     case 64: return launch_decode_t<64, false>(*p, groups, st);
     case 16: return launch_decode_t<16, false>(*p, groups, st);
     case 8: return launch_decode_t<8, false>(*p, groups, st);
-    case 4: return launch_decode_t<4, false>(*p, groups, st);
-    case 1: return launch_decode_t<1, false>(*p, groups, st);
+    }
+    return -1;
+}
+
+template <int G>
+static int launch_flat_t(const ys_params &p, u32 groups, hipStream_t st)
+{
+    u32 per_block = 256 / G;
+    u32 blocks = (groups + per_block - 1) / per_block;
+    hipLaunchKernelGGL((k_decode_flat<G>), dim3(blocks), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+
+/* the batch (flat) kernel: lanes_per_stream 1, 2 or 4 */
+extern "C" int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, unsigned groups, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    switch (lanes_per_stream) {
+    case 1: return launch_flat_t<1>(*p, groups, st);
+    case 2: return launch_flat_t<2>(*p, groups, st);
+    case 4: return launch_flat_t<4>(*p, groups, st);
     }
     return -1;
 }

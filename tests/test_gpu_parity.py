@@ -69,7 +69,7 @@ def test_misc_encoder_parameters():
         assert "%08x" % r[4] == m["crc32c"]
 
 
-@pytest.mark.parametrize("lanes", [64, 16, 8, 4, 1])
+@pytest.mark.parametrize("lanes", [64, 16, 8, 4, 2, 1])
 def test_cfg2_batch_every_group_width(lanes, monkeypatch):
     meta, streams = H.packed_streams("cfg2_streams")
     monkeypatch.setenv("YEAST_LANES", str(lanes))
