@@ -43,7 +43,21 @@ struct Shared {
     u64 cmd[704];
     u8 lut[768];
     u32 dict[32];
+    u32 xf[128]; /* first word of each transform record: op | omit << 8 | prefix len << 16 | suffix len << 24 */
 };
+
+DEV void shared_fill(Shared &sh, const u8 *xforms)
+{
+    for (u32 i = threadIdx.x; i < 704; i += blockDim.x)
+        sh.cmd[i] = c_cmd_tab[i];
+    for (u32 i = threadIdx.x; i < 768; i += blockDim.x)
+        sh.lut[i] = c_ctx_lut[i];
+    if (threadIdx.x < 32)
+        sh.dict[threadIdx.x] = c_dict_tab[threadIdx.x];
+    if (threadIdx.x < 128)
+        sh.xf[threadIdx.x] = threadIdx.x < 121 ? *(const u32 *)(xforms + 20 * threadIdx.x) : 0;
+    __syncthreads();
+}
 
 /* every access below is to global memory: say so, or pointers that travelled through an
    out-of-line call are treated as generic and cost flat_* instructions */
@@ -586,6 +600,16 @@ NOINL Hdr read_context_map(Hdr h, u8 *map, u32 len, u32 trees)
 
 /* ------------------------------------------------------------------ state */
 
+/* per-wavefront LDS of the batch kernel: the copy queues and the literal table map */
+#define FQ 8
+template <int G>
+struct WaveLds {
+    u32 qa[FQ * 64 / G]; /* destination, bytes from the start of the meta-block's output */
+    u32 qb[FQ * 64 / G]; /* bytes to produce */
+    u32 qc[FQ * 64 / G]; /* distance, or bit 31 | word length << 26 | dictionary id */
+    u32 lt[64 * 64 / G]; /* [context][stream]: byte offset of the literal table */
+};
+
 struct Blk { /* one block category: yeast.c:112-123 */
     u32 num, type, prev, left;
     u32 t_type, t_count; /* byte offsets of the two block-switch tables from ws */
@@ -609,6 +633,7 @@ struct Ctx {
     u64 need; /* output bytes required when rc == YS_CAPACITY */
     const u8 *dict, *xf;
     const Shared *sh;
+    void *wl; /* WaveLds<G> of this wavefront (batch kernel only) */
 };
 
 DEV const u16 *tab_at(const Ctx &c, u32 off) { return (const u16 *)(c.ws + off); }
@@ -765,6 +790,173 @@ DEV void emit_copy_wild(Ctx &c, u32 n, u32 d, u32 sub, bool ctx)
         }
     }
     c.outp += n;
+}
+
+/* A static dictionary reference resolved to pointers and lengths
+   (dict_word(): yeast.c:908-949). */
+struct DictRef {
+    const u8 *w, *t;
+    u32 op, plen, slen, wlen, wskip, copy, total;
+};
+
+/* validation part of dict_word(); false = invalid reference (code 3) */
+DEV bool dict_prepare(const Ctx &c, u32 copy, u64 id, DictRef &d)
+{
+    if (copy > 24 || copy < 4)
+        return false; /* :921-924 */
+    u32 de = c.sh->dict[copy];
+    u32 nd = de >> 24;
+    u64 xform = id >> nd;
+    if (xform >= 121)
+        return false; /* :929-930 */
+    u32 index = (u32)id & ((1u << nd) - 1);
+    d.w = c.dict + (de & 0xffffff) + index * copy;
+    d.t = c.xf + 20 * (u32)xform;
+    u32 hdr = c.sh->xf[(u32)xform];
+    u32 omit = (hdr >> 8) & 255;
+    d.op = hdr & 255;
+    d.plen = (hdr >> 16) & 255;
+    d.slen = hdr >> 24;
+    d.copy = copy;
+    d.wlen = copy;
+    d.wskip = 0;
+    if (d.op == 3) { /* omit first */
+        d.wlen = copy > omit ? copy - omit : 0;
+        d.wskip = d.wlen ? omit : 0;
+    } else if (d.op == 4)
+        d.wlen = copy > omit ? copy - omit : 0;
+    d.total = d.plen + d.wlen + d.slen;
+    return true;
+}
+
+/* uppercase masks (UPPER(): yeast.c:809-827): bit j set -> word byte j is xor-ed with 32 / with 5 */
+DEV void dict_masks(const DictRef &d, u32 &x32, u32 &x5)
+{
+    x32 = x5 = 0;
+    if (d.op == 1 || d.op == 2) {
+        u32 j = 0;
+        do {
+            u32 ch = gld8(d.w + j);
+            if (ch < 192) {
+                if (ch >= 97 && ch <= 122)
+                    x32 |= 1u << j;
+                j += 1;
+            } else if (ch < 224) {
+                if (j + 1 < d.copy)
+                    x32 |= 1u << (j + 1);
+                j += 2;
+            } else {
+                if (j + 2 < d.copy)
+                    x5 |= 1u << (j + 2);
+                j += 3;
+            }
+        } while (d.op == 2 && j < d.copy);
+    }
+}
+
+DEV u32 dict_byte(const DictRef &d, u32 x32, u32 x5, u32 k)
+{
+    u32 v;
+    if (k < d.plen)
+        v = gld8(d.t + 4 + k);
+    else if (k < d.plen + d.wlen) {
+        u32 j = k - d.plen + d.wskip;
+        v = gld8(d.w + j);
+        v ^= ((x32 >> j) & 1) << 5;
+        v ^= ((x5 >> j) & 1) * 5;
+    } else
+        v = gld8(d.t + 12 + k - d.plen - d.wlen);
+    return v;
+}
+
+/* exactly n (0..8) bytes of v to p, with at most four stores and no loop */
+DEV void put_le(u8 *p, u64 v, u32 n)
+{
+    if (n >= 8) {
+        gst64u(p, v);
+        return;
+    }
+    u32 o = 0;
+    if (n & 4) {
+        typedef u32 __attribute__((aligned(1))) u32u;
+        *(GAS u32u *)p = (u32)v;
+        o = 4;
+    }
+    if (n & 2) {
+        typedef u16 __attribute__((aligned(1))) u16u;
+        *(GAS u16u *)(p + o) = (u16)(v >> (8 * o));
+        o += 2;
+    }
+    if (n & 1)
+        gst8(p + o, (u32)(v >> (8 * o)) & 255);
+}
+
+/* Write a dictionary word with no byte loop and without touching a byte beyond its end.
+   Every lane of the group issues the same stores. */
+DEV void dict_write_exact(const DictRef &d, u8 *dst)
+{
+    u32 x32, x5;
+    dict_masks(d, x32, x5);
+    const u8 *w = d.w + d.wskip;
+    u64 pre = gld64u(d.t + 4), suf = gld64u(d.t + 12);
+    u64 w0 = gld64u(w), w1 = gld64u(w + 8), w2 = gld64u(w + 16);
+    if (x32 | x5) { /* spread the per-byte masks (wskip is 0 for the uppercase transforms) */
+        u64 m0 = 0, m1 = 0, m2 = 0;
+        for (u32 j = 0; j < 8; j++) {
+            m0 |= (u64)((((x32 >> j) & 1) << 5) | (((x5 >> j) & 1) * 5)) << (8 * j);
+            m1 |= (u64)((((x32 >> (j + 8)) & 1) << 5) | (((x5 >> (j + 8)) & 1) * 5)) << (8 * j);
+            m2 |= (u64)((((x32 >> (j + 16)) & 1) << 5) | (((x5 >> (j + 16)) & 1) * 5)) << (8 * j);
+        }
+        w0 ^= m0;
+        w1 ^= m1;
+        w2 ^= m2;
+    }
+    put_le(dst, pre, d.plen);
+    u8 *wd = dst + d.plen;
+    u32 wl = d.wlen;
+    put_le(wd, w0, wl);
+    if (wl > 8)
+        put_le(wd + 8, w1, wl - 8);
+    if (wl > 16)
+        put_le(wd + 16, w2, wl - 16);
+    put_le(wd + wl, suf, d.slen);
+}
+
+/* LZ77 copy with no byte tail loop and without touching a byte beyond dst + n. */
+template <int G>
+DEV void copy_exact(u8 *dst, u32 n, u32 d, u32 sub)
+{
+    const u8 *from = dst - d;
+    if (d >= n || (G == 1 && d >= 8)) {
+        if (n >= 8) {
+            for (u32 j = sub * 8; j + 8 <= n; j += G * 8)
+                gst64u(dst + j, gld64u(from + j));
+            if ((n & 7) && (G == 1 || sub == ((n >> 3) & (G - 1))))
+                gst64u(dst + n - 8, gld64u(from + n - 8));
+        } else if (G == 1 || sub == 0) {
+            u32 o = 0;
+            if (n & 4) {
+                typedef u32 __attribute__((aligned(1))) u32u;
+                *(GAS u32u *)dst = *(const GAS u32u *)from;
+                o = 4;
+            }
+            if (n & 2) {
+                typedef u16 __attribute__((aligned(1))) u16u;
+                *(GAS u16u *)(dst + o) = *(const GAS u16u *)(from + o);
+                o += 2;
+            }
+            if (n & 1)
+                gst8(dst + o, gld8(from + o));
+        }
+    } else { /* overlapping: byte i repeats byte i mod d of the source */
+        u32 m = sub % d, step = G % d;
+        for (u32 i = sub; i < n; i += G) {
+            gst8(dst + i, gld8(from + m));
+            m += step;
+            if (m >= d)
+                m -= d;
+        }
+    }
 }
 
 /* dict_word(): yeast.c:908-949 with the elementary transforms :799-879.
@@ -1146,12 +1338,28 @@ DEV u32 metablock(Ctx &c, u32 sub)
         /* ---- the same command loop as a flat state machine: every trip decodes exactly
            one prefix code symbol per stream (insert-and-copy, literal or distance), so the
            streams that share a wavefront stay converged on the expensive part -- the table
-           lookup -- whatever mix of commands they are in.  yeast.c:1166-1295. ---- */
+           lookup -- whatever mix of commands they are in.  Window copies and dictionary
+           words are not executed where they are decoded: they go to a short per-stream
+           queue in LDS and the whole wavefront drains its queues together (the "second
+           pass" that resolves LZ77 and dictionary references).  yeast.c:1166-1295. ---- */
         enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3 };
+        WaveLds<G> *wl = (WaveLds<G> *)c.wl;
+        const u32 slot = (threadIdx.x & 63) / G;
+        constexpr u32 S = 64 / G;
         u32 st = ST_CMD;
         u32 offI = gld32(itab), offL = (u32)((const u8 *)tL0 - c.ws), offD0 = (u32)((const u8 *)tD0 - c.ws);
         u32 insert = 0, copy = 0, implicit = 0;
-        u8 *const out_end = c.out + c.cap;
+        u8 *const mb_base = c.outp; /* queue entries hold offsets from here (mlen < 2^25) */
+        u32 qn = 0, pend_rel = 0, stale = 0;
+        const bool lds_lt = ctx && c.L.num == 1;
+        if (lds_lt) { /* the 64 table offsets of the only literal block type move to LDS */
+            for (n = sub; n < 64; n += G)
+                wl->lt[n * S + slot] = gld32(lit_tab + n);
+        }
+        auto next_lit_table = [&]() -> u32 {
+            u32 id = (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode);
+            return lds_lt ? wl->lt[id * S + slot] : gld32(lit_tab + id);
+        };
         while (st != ST_END) {
             u32 off;
             if (st == ST_CMD) {
@@ -1169,7 +1377,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
                         switch_block(c, c.L);
                         cur_mode = gld8(mode + c.L.type);
                         if (ctx)
-                            offL = gld32(lit_tab + (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode));
+                            offL = next_lit_table();
                     }
                     c.L.left--;
                 }
@@ -1255,31 +1463,109 @@ DEV u32 metablock(Ctx &c, u32 sub)
                 do_copy = true;
             }
             if (do_copy) {
+                /* validate and account for the copy now; queue the byte moving */
                 u64 got = got_of(c);
                 u32 max = got > c.wsize ? c.wsize : (u32)got;
                 if (dist <= 0) {
                     rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
                     break;
                 }
+                u32 rel = (u32)(c.outp - mb_base), nout, ref;
                 if (dist > (i64)max) {
-                    emit_dict<G, false>(c, copy, (u64)dist - max - 1, mlen, sub, ctx);
+                    DictRef dr;
+                    u64 id = (u64)dist - max - 1;
+                    if (!dict_prepare(c, copy, id, dr) || dr.total > mlen) {
+                        rd_fail(r, YS_INVALID); /* :921-930, :1269 */
+                        break;
+                    }
+                    nout = dr.total;
+                    ref = 0x80000000u | (u32)id | (copy << 26); /* id < 121 << 11 < 2^18 */
+                    if (ctx && nout) {
+                        u32 x32, x5;
+                        dict_masks(dr, x32, x5);
+                        if (nout >= 2) {
+                            c.p1 = dict_byte(dr, x32, x5, nout - 1);
+                            c.p2 = dict_byte(dr, x32, x5, nout - 2);
+                            stale = 0;
+                        } else {
+                            c.p2 = c.p1;
+                            c.p1 = dict_byte(dr, x32, x5, 0);
+                        }
+                    }
                 } else {
                     if (copy > mlen) {
                         rd_fail(r, YS_INVALID); /* :1283 */
                         break;
                     }
-                    mlen -= copy;
-                    if (c.outp + copy + 16 <= out_end)
-                        emit_copy_wild<G>(c, copy, (u32)dist, sub, ctx);
-                    else
-                        emit_copy<G, false>(c, copy, (u32)dist, sub, ctx);
+                    nout = copy;
+                    ref = (u32)dist;
+                    if (ctx) {
+                        /* the last two bytes of the copy, straight from its source when that
+                           is final already: not overlapping and not behind a queued write */
+                        u32 first = qn ? pend_rel : rel;
+                        if ((u32)dist >= copy && (i64)rel + copy - dist <= (i64)first) {
+                            const u8 *e = c.outp - dist + copy;
+                            c.p1 = gld8(e - 1);
+                            c.p2 = gld8(e - 2);
+                            stale = 0;
+                        } else
+                            stale = 1;
+                    }
                 }
-                if (r.rc)
-                    break;
+                mlen -= nout;
+                if (nout) {
+                    if (qn == 0)
+                        pend_rel = rel;
+                    wl->qa[qn * S + slot] = rel;
+                    wl->qb[qn * S + slot] = nout;
+                    wl->qc[qn * S + slot] = ref;
+                    qn++;
+                }
+                c.outp += nout;
                 st = mlen ? ST_CMD : ST_END;
             }
-            if (st == ST_LIT && ctx)
-                offL = gld32(lit_tab + (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode));
+            /* second pass, the whole wavefront at once: when some queue is full or some
+               stream needs bytes that are still queued */
+            bool need = st == ST_LIT && ctx && stale;
+            if (__any(qn == FQ || need)) {
+                for (u32 k = 0; k < qn; k++) {
+                    u32 qa = wl->qa[k * S + slot], qb = wl->qb[k * S + slot], qc = wl->qc[k * S + slot];
+                    u8 *dst = mb_base + qa;
+                    if (qc >> 31) {
+                        DictRef dr;
+                        dict_prepare(c, (qc >> 26) & 31, qc & 0x3ffffu, dr);
+                        dict_write_exact(dr, dst);
+                    } else
+                        copy_exact<G>(dst, qb, qc, sub);
+                }
+                qn = 0;
+                if (need) {
+                    group_sync_mem();
+                    c.p1 = gld8(c.outp - 1);
+                    c.p2 = gld8(c.outp - 2);
+                }
+                if (need)
+                    stale = 0;
+            }
+            if (st == ST_LIT && ctx) {
+                offL = next_lit_table();
+            }
+        }
+        /* metablock end (or failure): drain what is queued -- everything queued was valid */
+        for (u32 k = 0; k < qn; k++) {
+            u32 qa = wl->qa[k * S + slot], qb = wl->qb[k * S + slot], qc = wl->qc[k * S + slot];
+            u8 *dst = mb_base + qa;
+            if (qc >> 31) {
+                DictRef dr;
+                dict_prepare(c, (qc >> 26) & 31, qc & 0x3ffffu, dr);
+                dict_write_exact(dr, dst);
+            } else
+                copy_exact<G>(dst, qb, qc, sub);
+        }
+        if (stale && got_of(c) >= 2) { /* context for the next meta-block */
+            group_sync_mem();
+            c.p1 = gld8(c.outp - 1);
+            c.p2 = gld8(c.outp - 2);
         }
     }
     if (!r.rc && last && tail_nonzero(r))
@@ -1289,7 +1575,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
 
 /* yeast(): yeast.c:1353-1400 for one stream of the batch */
 template <int G, bool CMP, bool FLAT>
-DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub)
+DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub, void *wl = nullptr)
 {
     Ctx c;
     u64 s0 = p.src_off[job], s1 = p.src_off[job + 1];
@@ -1311,6 +1597,7 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     c.dict = p.dict;
     c.xf = p.xforms;
     c.sh = sh;
+    c.wl = wl;
     c.L.num = c.I.num = c.D.num = 1;
     rd_seek(c.r, c.src, 0);
     if (s1 - s0 >= (1u << 29))
@@ -1354,13 +1641,7 @@ template <int G, bool CMP>
 __global__ __launch_bounds__(256, YS_MIN_WAVES) void k_decode(ys_params p)
 {
     __shared__ Shared sh;
-    for (u32 i = threadIdx.x; i < 704; i += blockDim.x)
-        sh.cmd[i] = c_cmd_tab[i];
-    for (u32 i = threadIdx.x; i < 768; i += blockDim.x)
-        sh.lut[i] = c_ctx_lut[i];
-    if (threadIdx.x < 32)
-        sh.dict[threadIdx.x] = c_dict_tab[threadIdx.x];
-    __syncthreads();
+    shared_fill(sh, p.xforms);
     u32 lane = threadIdx.x;
     u32 sub = lane & (G - 1);
     u32 gid = (blockIdx.x * blockDim.x + lane) / G;
@@ -1387,13 +1668,8 @@ template <int G>
 __global__ __launch_bounds__(256, 1) void k_decode_flat(ys_params p)
 {
     __shared__ Shared sh;
-    for (u32 i = threadIdx.x; i < 704; i += blockDim.x)
-        sh.cmd[i] = c_cmd_tab[i];
-    for (u32 i = threadIdx.x; i < 768; i += blockDim.x)
-        sh.lut[i] = c_ctx_lut[i];
-    if (threadIdx.x < 32)
-        sh.dict[threadIdx.x] = c_dict_tab[threadIdx.x];
-    __syncthreads();
+    __shared__ WaveLds<G> wlds[4];
+    shared_fill(sh, p.xforms);
     u32 lane = threadIdx.x;
     u32 sub = lane & (G - 1);
     u32 gid = (blockIdx.x * blockDim.x + lane) / G;
@@ -1410,7 +1686,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_flat(ys_params p)
         if (job < limit) {
             if (p.retry)
                 job = p.retry_list[job];
-            decode_stream<G, false, true>(p, job, ws, &sh, sub);
+            decode_stream<G, false, true>(p, job, ws, &sh, sub, &wlds[lane >> 6]);
         }
     }
 }

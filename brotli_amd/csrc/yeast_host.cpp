@@ -160,7 +160,8 @@ static int device_get(Device **out)
             e = ys_upload_check_constants(x2n);
         if (e)
             return fail("upload constants (is a gfx950 code object present?)", (hipError_t)e);
-        HIPCK(hipMalloc((void **)&d.d_dict, sizeof(ys_dictionary)));
+        HIPCK(hipMalloc((void **)&d.d_dict, sizeof(ys_dictionary) + 64)); /* words are read 8 bytes at a time */
+        HIPCK(hipMemset(d.d_dict, 0, sizeof(ys_dictionary) + 64));
         HIPCK(hipMalloc((void **)&d.d_xf, 4096));
         HIPCK(hipMemcpy(d.d_dict, ys_dictionary, sizeof(ys_dictionary), hipMemcpyHostToDevice));
         HIPCK(hipMemcpy(d.d_xf, ys_transforms, sizeof(ys_transforms), hipMemcpyHostToDevice));
