@@ -201,7 +201,7 @@ def main():
                                % (n, len(distinct), {0: "no", 1: "CRC-32C", 2: "XXH32", 3: "XXH64"}[args.check],
                                   " + RCCL all-gather of records" if world > 1 else ""),
                    "streams_per_gpu": n, "out_bytes_per_gpu": out_bytes, "in_bytes_per_gpu": in_bytes,
-                   "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "8")),
+                   "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "1")),
                    "parallelism": "%d independent shards" % world},
         "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

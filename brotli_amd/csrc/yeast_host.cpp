@@ -217,7 +217,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         return -1;
     }
     if (lanes == 0)
-        lanes = env_int("YEAST_LANES", 8);
+        lanes = env_int("YEAST_LANES", 1);
     if (cmp)
         lanes = 64;
     if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 64) {
