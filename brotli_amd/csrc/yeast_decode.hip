@@ -44,6 +44,7 @@ struct Shared {
     u8 lut[768];
     u32 dict[32];
     u32 xf[128]; /* first word of each transform record: op | omit << 8 | prefix len << 16 | suffix len << 24 */
+    u64 xpre[128], xsuf[128]; /* prefix and suffix bytes of each transform, little endian */
 };
 
 DEV void shared_fill(Shared &sh, const u8 *xforms)
@@ -54,8 +55,13 @@ DEV void shared_fill(Shared &sh, const u8 *xforms)
         sh.lut[i] = c_ctx_lut[i];
     if (threadIdx.x < 32)
         sh.dict[threadIdx.x] = c_dict_tab[threadIdx.x];
-    if (threadIdx.x < 128)
-        sh.xf[threadIdx.x] = threadIdx.x < 121 ? *(const u32 *)(xforms + 20 * threadIdx.x) : 0;
+    if (threadIdx.x < 128) {
+        u32 i = threadIdx.x;
+        const u32 *rec = (const u32 *)(xforms + 20 * i);
+        sh.xf[i] = i < 121 ? rec[0] : 0;
+        sh.xpre[i] = i < 121 ? (u64)rec[1] | ((u64)rec[2] << 32) : 0;
+        sh.xsuf[i] = i < 121 ? (u64)rec[3] | ((u64)rec[4] << 32) : 0;
+    }
     __syncthreads();
 }
 
@@ -796,7 +802,7 @@ DEV void emit_copy_wild(Ctx &c, u32 n, u32 d, u32 sub, bool ctx)
    (dict_word(): yeast.c:908-949). */
 struct DictRef {
     const u8 *w, *t;
-    u32 op, plen, slen, wlen, wskip, copy, total;
+    u32 op, plen, slen, wlen, wskip, copy, total, xform;
 };
 
 /* validation part of dict_word(); false = invalid reference (code 3) */
@@ -812,6 +818,7 @@ DEV bool dict_prepare(const Ctx &c, u32 copy, u64 id, DictRef &d)
     u32 index = (u32)id & ((1u << nd) - 1);
     d.w = c.dict + (de & 0xffffff) + index * copy;
     d.t = c.xf + 20 * (u32)xform;
+    d.xform = (u32)xform;
     u32 hdr = c.sh->xf[(u32)xform];
     u32 omit = (hdr >> 8) & 255;
     d.op = hdr & 255;
@@ -1335,20 +1342,24 @@ DEV u32 metablock(Ctx &c, u32 sub)
             }
         } while (mlen && !r.rc);
     } else {
-        /* ---- the same command loop as a flat state machine: every trip decodes exactly
-           one prefix code symbol per stream (insert-and-copy, literal or distance), so the
-           streams that share a wavefront stay converged on the expensive part -- the table
-           lookup -- whatever mix of commands they are in.  Window copies and dictionary
-           words are not executed where they are decoded: they go to a short per-stream
-           queue in LDS and the whole wavefront drains its queues together (the "second
-           pass" that resolves LZ77 and dictionary references).  yeast.c:1166-1295. ---- */
+        /* ---- the same command loop as a flat state machine: every trip performs exactly
+           one table lookup per stream (an insert-and-copy, literal or distance symbol, or the
+           second level of a long code), so the streams that share a wavefront stay converged
+           on the expensive part whatever mix of commands they are in.  Window copies and
+           dictionary words are validated and accounted for where they are decoded, but their
+           bytes are moved later: they go to a short per-stream queue in LDS and the whole
+           wavefront drains its queues together (the "second pass" that resolves LZ77 and
+           dictionary references).  yeast.c:1166-1295. ---- */
         enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3 };
         WaveLds<G> *wl = (WaveLds<G> *)c.wl;
         const u32 slot = (threadIdx.x & 63) / G;
         constexpr u32 S = 64 / G;
         u32 st = ST_CMD;
         u32 offI = gld32(itab), offL = (u32)((const u8 *)tL0 - c.ws), offD0 = (u32)((const u8 *)tD0 - c.ws);
+        u32 off = offI;
         u32 insert = 0, copy = 0, implicit = 0;
+        u32 link = 0;   /* root entry of a long code whose second lookup is this trip's work */
+        u32 pn = 0, pn_valid = 0; /* last two bytes of the newest copy, loads still in flight */
         u8 *const mb_base = c.outp; /* queue entries hold offsets from here (mlen < 2^25) */
         u32 qn = 0, pend_rel = 0, stale = 0;
         const bool lds_lt = ctx && c.L.num == 1;
@@ -1360,39 +1371,125 @@ DEV u32 metablock(Ctx &c, u32 sub)
             u32 id = (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode);
             return lds_lt ? wl->lt[id * S + slot] : gld32(lit_tab + id);
         };
-        while (st != ST_END) {
-            u32 off;
-            if (st == ST_CMD) {
-                if (c.I.num > 1) {
-                    if (c.I.left == 0) {
-                        switch_block(c, c.I);
-                        offI = gld32(itab + c.I.type);
+        /* second pass over one stream's queue: one load round trip per entry */
+        auto drain = [&]() {
+            for (u32 k = 0; k < qn; k++) {
+                u32 qa = wl->qa[k * S + slot], qb = wl->qb[k * S + slot], qc = wl->qc[k * S + slot];
+                u8 *dst = mb_base + qa;
+                const u8 *src;
+                u32 len, plen = 0, slen = 0, x32 = 0, x5 = 0;
+                u64 pre = 0, suf = 0;
+                bool slow;
+                if (qc >> 31) {
+                    DictRef dr;
+                    dict_prepare(c, (qc >> 26) & 31, qc & 0x3ffffu, dr);
+                    if (dr.op == 1 || dr.op == 2)
+                        dict_masks(dr, x32, x5);
+                    src = dr.w + dr.wskip;
+                    len = dr.wlen;
+                    plen = dr.plen;
+                    slen = dr.slen;
+                    pre = c.sh->xpre[dr.xform];
+                    suf = c.sh->xsuf[dr.xform];
+                    slow = false;
+                } else {
+                    src = dst - qc;
+                    len = qb;
+                    slow = qc < qb || qb > 24; /* overlapping or long: the general copier */
+                }
+                if (slow) {
+                    copy_exact<G>(dst, qb, qc, sub);
+                } else {
+                    u64 c0 = 0, c1 = 0, c2 = 0;
+                    if (len)
+                        c0 = gld64u(src);
+                    if (len > 8)
+                        c1 = gld64u(src + 8);
+                    if (len > 16)
+                        c2 = gld64u(src + 16);
+                    if (x32 | x5) {
+                        u64 m0 = 0, m1 = 0, m2 = 0;
+                        for (u32 j = 0; j < 8; j++) {
+                            m0 |= (u64)((((x32 >> j) & 1) << 5) | (((x5 >> j) & 1) * 5)) << (8 * j);
+                            m1 |= (u64)((((x32 >> (j + 8)) & 1) << 5) | (((x5 >> (j + 8)) & 1) * 5)) << (8 * j);
+                            m2 |= (u64)((((x32 >> (j + 16)) & 1) << 5) | (((x5 >> (j + 16)) & 1) * 5)) << (8 * j);
+                        }
+                        c0 ^= m0;
+                        c1 ^= m1;
+                        c2 ^= m2;
                     }
-                    c.I.left--;
-                }
-                off = offI;
-            } else if (st == ST_LIT) {
-                if (c.L.num > 1) {
-                    if (c.L.left == 0) {
-                        switch_block(c, c.L);
-                        cur_mode = gld8(mode + c.L.type);
-                        if (ctx)
-                            offL = next_lit_table();
+                    if (G == 1 || sub == 0) {
+                        u8 *wd = dst + plen;
+                        put_le(dst, pre, plen);
+                        put_le(wd, c0, len);
+                        if (len > 8)
+                            put_le(wd + 8, c1, len - 8);
+                        if (len > 16)
+                            put_le(wd + 16, c2, len - 16);
+                        put_le(wd + len, suf, slen);
                     }
-                    c.L.left--;
                 }
-                off = offL;
-            } else {
-                if (c.D.num > 1) {
-                    if (c.D.left == 0)
-                        switch_block(c, c.D);
-                    c.D.left--;
-                }
-                off = offD0;
-                if (c.dist_codes > 1)
-                    off = gld32(dtab + (c.D.type << 2) + (copy > 4 ? 3 : copy - 2));
             }
-            u32 sym = dec_sym(r, (const u16 *)(c.ws + off));
+            qn = 0;
+        };
+        while (st != ST_END) {
+            if (!link) {
+                if (st == ST_CMD) {
+                    if (c.I.num > 1) {
+                        if (c.I.left == 0) {
+                            switch_block(c, c.I);
+                            offI = gld32(itab + c.I.type);
+                        }
+                        c.I.left--;
+                    }
+                    off = offI;
+                } else if (st == ST_LIT) {
+                    if (c.L.num > 1) {
+                        if (c.L.left == 0) {
+                            switch_block(c, c.L);
+                            cur_mode = gld8(mode + c.L.type);
+                            if (ctx)
+                                offL = next_lit_table();
+                        }
+                        c.L.left--;
+                    }
+                    off = offL;
+                } else {
+                    if (c.D.num > 1) {
+                        if (c.D.left == 0)
+                            switch_block(c, c.D);
+                        c.D.left--;
+                    }
+                    off = offD0;
+                    if (c.dist_codes > 1)
+                        off = gld32(dtab + (c.D.type << 2) + (copy > 4 ? 3 : copy - 2));
+                }
+            }
+            /* the one table lookup of this trip */
+            rd_refill(r);
+            u32 peek = (u32)r.w;
+            u32 idx = link ? (link >> 4) + ((peek >> ROOT) & ((1u << ((link & 15) - ROOT)) - 1)) : (peek & 255);
+            u32 e = gld16((const u16 *)(c.ws + off) + idx);
+            if (pn_valid) { /* issued before the lookup above, so it has arrived with it */
+                c.p1 = pn >> 8;
+                c.p2 = pn & 255;
+                pn_valid = 0;
+            }
+            if (!link && (e & 15) > ROOT) {
+                link = e;
+                continue;
+            }
+            link = 0;
+            {
+                u32 l = e & 15;
+                if (l > r.have) {
+                    rd_eof(r);
+                    l = 0;
+                }
+                r.w >>= l;
+                r.have -= l;
+            }
+            u32 sym = e >> 4;
             if (r.rc)
                 break;
             bool do_copy = false;
@@ -1481,16 +1578,24 @@ DEV u32 metablock(Ctx &c, u32 sub)
                     nout = dr.total;
                     ref = 0x80000000u | (u32)id | (copy << 26); /* id < 121 << 11 < 2^18 */
                     if (ctx && nout) {
-                        u32 x32, x5;
-                        dict_masks(dr, x32, x5);
-                        if (nout >= 2) {
-                            c.p1 = dict_byte(dr, x32, x5, nout - 1);
-                            c.p2 = dict_byte(dr, x32, x5, nout - 2);
+                        /* last two bytes of the transformed word: suffix and prefix bytes are in
+                           LDS; raw dictionary bytes are fetched (arriving with the next lookup);
+                           the few cases that need the uppercase rules wait for the drain */
+                        if (dr.slen >= 2) {
+                            u64 sf = c.sh->xsuf[dr.xform] >> (8 * (dr.slen - 2));
+                            c.p2 = (u32)sf & 255;
+                            c.p1 = (u32)(sf >> 8) & 255;
                             stale = 0;
-                        } else {
-                            c.p2 = c.p1;
-                            c.p1 = dict_byte(dr, x32, x5, 0);
-                        }
+                        } else if (dr.wlen >= 2 + (1 - dr.slen) && dr.op != 2 && !(dr.op == 1 && dr.wlen < 5)) {
+                            const u8 *we = dr.w + dr.wskip + dr.wlen;
+                            if (dr.slen == 1) {
+                                pn = (((u32)c.sh->xsuf[dr.xform] & 255) << 8) | gld8(we - 1);
+                            } else
+                                pn = (gld8(we - 1) << 8) | gld8(we - 2);
+                            pn_valid = 1;
+                            stale = 0;
+                        } else
+                            stale = 1;
                     }
                 } else {
                     if (copy > mlen) {
@@ -1504,9 +1609,9 @@ DEV u32 metablock(Ctx &c, u32 sub)
                            is final already: not overlapping and not behind a queued write */
                         u32 first = qn ? pend_rel : rel;
                         if ((u32)dist >= copy && (i64)rel + copy - dist <= (i64)first) {
-                            const u8 *e = c.outp - dist + copy;
-                            c.p1 = gld8(e - 1);
-                            c.p2 = gld8(e - 2);
+                            const u8 *e2 = c.outp - dist + copy;
+                            pn = (gld8(e2 - 1) << 8) | gld8(e2 - 2);
+                            pn_valid = 1;
                             stale = 0;
                         } else
                             stale = 1;
@@ -1528,39 +1633,22 @@ DEV u32 metablock(Ctx &c, u32 sub)
                stream needs bytes that are still queued */
             bool need = st == ST_LIT && ctx && stale;
             if (__any(qn == FQ || need)) {
-                for (u32 k = 0; k < qn; k++) {
-                    u32 qa = wl->qa[k * S + slot], qb = wl->qb[k * S + slot], qc = wl->qc[k * S + slot];
-                    u8 *dst = mb_base + qa;
-                    if (qc >> 31) {
-                        DictRef dr;
-                        dict_prepare(c, (qc >> 26) & 31, qc & 0x3ffffu, dr);
-                        dict_write_exact(dr, dst);
-                    } else
-                        copy_exact<G>(dst, qb, qc, sub);
-                }
-                qn = 0;
+                drain();
                 if (need) {
                     group_sync_mem();
                     c.p1 = gld8(c.outp - 1);
                     c.p2 = gld8(c.outp - 2);
-                }
-                if (need)
                     stale = 0;
+                }
             }
-            if (st == ST_LIT && ctx) {
+            if (st == ST_LIT && ctx && !pn_valid)
                 offL = next_lit_table();
-            }
         }
         /* metablock end (or failure): drain what is queued -- everything queued was valid */
-        for (u32 k = 0; k < qn; k++) {
-            u32 qa = wl->qa[k * S + slot], qb = wl->qb[k * S + slot], qc = wl->qc[k * S + slot];
-            u8 *dst = mb_base + qa;
-            if (qc >> 31) {
-                DictRef dr;
-                dict_prepare(c, (qc >> 26) & 31, qc & 0x3ffffu, dr);
-                dict_write_exact(dr, dst);
-            } else
-                copy_exact<G>(dst, qb, qc, sub);
+        drain();
+        if (pn_valid) {
+            c.p1 = pn >> 8;
+            c.p2 = pn & 255;
         }
         if (stale && got_of(c) >= 2) { /* context for the next meta-block */
             group_sync_mem();
