@@ -1475,35 +1475,32 @@ DEV u32 metablock(Ctx &c, u32 sub)
                 c.p2 = pn & 255;
                 pn_valid = 0;
             }
-            if (!link && (e & 15) > ROOT) {
+            /* what this trip does with the entry: 4 = nothing yet (first half of a long code) */
+            u32 act = st;
+            u32 l = e & 15;
+            if (!link && l > ROOT) {
                 link = e;
-                continue;
+                act = 4;
+                l = 0;
+            } else
+                link = 0;
+            if (l > r.have) {
+                rd_eof(r);
+                l = 0;
             }
-            link = 0;
-            {
-                u32 l = e & 15;
-                if (l > r.have) {
-                    rd_eof(r);
-                    l = 0;
-                }
-                r.w >>= l;
-                r.have -= l;
-            }
-            u32 sym = e >> 4;
+            r.w >>= l;
+            r.have -= l;
             if (r.rc)
-                break;
+                act = 4;
+            u32 sym = e >> 4;
             bool do_copy = false;
             i64 dist = 0;
-            if (st == ST_CMD) {
+            if (act == ST_CMD) {
                 u64 ce = cmd_tab[sym < 704 ? sym : 0];
                 insert = ((u32)ce & 0xffff) + take(r, ((u32)ce >> 16) & 0xff);
                 copy = ((u32)(ce >> 24) & 0xffff) + take(r, (u32)(ce >> 40));
-                if (r.rc)
-                    break;
-                if (insert > mlen) {
+                if (!r.rc && insert > mlen)
                     rd_fail(r, YS_INVALID); /* :1189 */
-                    break;
-                }
                 mlen -= insert;
                 implicit = sym < 128;
                 if (insert)
@@ -1513,7 +1510,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
                     dist = c.r0;
                 } else
                     st = ST_DIST;
-            } else if (st == ST_LIT) {
+            } else if (act == ST_LIT) {
                 gst8(c.outp, sym);
                 c.outp++;
                 c.p2 = c.p1;
@@ -1527,7 +1524,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
                     } else
                         st = ST_DIST;
                 }
-            } else { /* distance(): yeast.c:761-789 */
+            } else if (act == ST_DIST) { /* distance(): yeast.c:761-789 */
                 u64 got = got_of(c);
                 u32 max = got > c.wsize ? c.wsize : (u32)got;
                 u32 ds = sym;
@@ -1552,56 +1549,50 @@ DEV u32 metablock(Ctx &c, u32 sub)
                     u64 o2 = ((u64)(2 + ((nn >> c.postfix) & 1)) << x) - 4;
                     dist = (i64)(((o2 + take(r, x)) << c.postfix) + (nn & ((1u << c.postfix) - 1)) + c.direct + 1);
                 }
-                if (r.rc)
-                    break;
-                if (ds && dist > 0 && dist <= (i64)max) {
+                if (!r.rc && ds && dist > 0 && dist <= (i64)max) {
                     c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
                 }
                 do_copy = true;
             }
-            if (do_copy) {
+            if (do_copy && !r.rc) {
                 /* validate and account for the copy now; queue the byte moving */
                 u64 got = got_of(c);
                 u32 max = got > c.wsize ? c.wsize : (u32)got;
+                u32 rel = (u32)(c.outp - mb_base), nout = 0, ref = 0;
                 if (dist <= 0) {
                     rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
-                    break;
-                }
-                u32 rel = (u32)(c.outp - mb_base), nout, ref;
-                if (dist > (i64)max) {
+                } else if (dist > (i64)max) {
                     DictRef dr;
                     u64 id = (u64)dist - max - 1;
                     if (!dict_prepare(c, copy, id, dr) || dr.total > mlen) {
                         rd_fail(r, YS_INVALID); /* :921-930, :1269 */
-                        break;
-                    }
-                    nout = dr.total;
-                    ref = 0x80000000u | (u32)id | (copy << 26); /* id < 121 << 11 < 2^18 */
-                    if (ctx && nout) {
-                        /* last two bytes of the transformed word: suffix and prefix bytes are in
-                           LDS; raw dictionary bytes are fetched (arriving with the next lookup);
-                           the few cases that need the uppercase rules wait for the drain */
-                        if (dr.slen >= 2) {
-                            u64 sf = c.sh->xsuf[dr.xform] >> (8 * (dr.slen - 2));
-                            c.p2 = (u32)sf & 255;
-                            c.p1 = (u32)(sf >> 8) & 255;
-                            stale = 0;
-                        } else if (dr.wlen >= 2 + (1 - dr.slen) && dr.op != 2 && !(dr.op == 1 && dr.wlen < 5)) {
-                            const u8 *we = dr.w + dr.wskip + dr.wlen;
-                            if (dr.slen == 1) {
-                                pn = (((u32)c.sh->xsuf[dr.xform] & 255) << 8) | gld8(we - 1);
+                    } else {
+                        nout = dr.total;
+                        ref = 0x80000000u | (u32)id | (copy << 26); /* id < 121 << 11 < 2^18 */
+                        if (ctx && nout) {
+                            /* last two bytes of the transformed word: suffix and prefix bytes are in
+                               LDS; raw dictionary bytes are fetched (arriving with the next lookup);
+                               the few cases that need the uppercase rules wait for the drain */
+                            if (dr.slen >= 2) {
+                                u64 sf = c.sh->xsuf[dr.xform] >> (8 * (dr.slen - 2));
+                                c.p2 = (u32)sf & 255;
+                                c.p1 = (u32)(sf >> 8) & 255;
+                                stale = 0;
+                            } else if (dr.wlen >= 2 + (1 - dr.slen) && dr.op != 2 && !(dr.op == 1 && dr.wlen < 5)) {
+                                const u8 *we = dr.w + dr.wskip + dr.wlen;
+                                if (dr.slen == 1) {
+                                    pn = (((u32)c.sh->xsuf[dr.xform] & 255) << 8) | gld8(we - 1);
+                                } else
+                                    pn = (gld8(we - 1) << 8) | gld8(we - 2);
+                                pn_valid = 1;
+                                stale = 0;
                             } else
-                                pn = (gld8(we - 1) << 8) | gld8(we - 2);
-                            pn_valid = 1;
-                            stale = 0;
-                        } else
-                            stale = 1;
+                                stale = 1;
+                        }
                     }
+                } else if (copy > mlen) {
+                    rd_fail(r, YS_INVALID); /* :1283 */
                 } else {
-                    if (copy > mlen) {
-                        rd_fail(r, YS_INVALID); /* :1283 */
-                        break;
-                    }
                     nout = copy;
                     ref = (u32)dist;
                     if (ctx) {
@@ -1629,6 +1620,8 @@ DEV u32 metablock(Ctx &c, u32 sub)
                 c.outp += nout;
                 st = mlen ? ST_CMD : ST_END;
             }
+            if (r.rc)
+                st = ST_END;
             /* second pass, the whole wavefront at once: when some queue is full or some
                stream needs bytes that are still queued */
             bool need = st == ST_LIT && ctx && stale;
@@ -1641,7 +1634,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
                     stale = 0;
                 }
             }
-            if (st == ST_LIT && ctx && !pn_valid)
+            if (st == ST_LIT && ctx)
                 offL = next_lit_table();
         }
         /* metablock end (or failure): drain what is queued -- everything queued was valid */
