@@ -76,6 +76,11 @@ DEV u64 gld64u(const void *p) /* unaligned */
     typedef u64 __attribute__((aligned(1))) u64u;
     return *(const GAS u64u *)p;
 }
+DEV u32 gld16u(const void *p) /* unaligned */
+{
+    typedef u16 __attribute__((aligned(1))) u16u;
+    return *(const GAS u16u *)p;
+}
 DEV void gst8(void *p, u32 v) { *(GAS u8 *)p = (u8)v; }
 DEV void gst16(void *p, u32 v) { *(GAS u16 *)p = (u16)v; }
 DEV void gst32(void *p, u32 v) { *(GAS u32 *)p = v; }
@@ -640,6 +645,9 @@ struct Ctx {
     const u8 *dict, *xf;
     const Shared *sh;
     void *wl; /* WaveLds<G> of this wavefront (batch kernel only) */
+#ifdef YS_PROFILE
+    u64 t_hdr, t_loop, t_drain;
+#endif
 };
 
 DEV const u16 *tab_at(const Ctx &c, u32 off) { return (const u16 *)(c.ws + off); }
@@ -1089,6 +1097,385 @@ DEV void emit_raw(Ctx &c, const u8 *from, u32 n, u32 sub)
 /* the bytes a group has just written become visible to its own later loads */
 DEV void group_sync_mem() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
+/* ------------------------------------------------ batch kernel command loop */
+
+struct FlatEnv {
+    const u32 *itab, *dtab, *lit_tab;
+    const u8 *mode;
+    u32 offL0, offD0, cur_mode;
+    bool ctx;
+};
+
+/* spread the low 8 bits of b to the low bit of 8 bytes */
+DEV u64 spread8(u32 b)
+{
+    u64 x = b & 255;
+    x = (x | (x << 28)) & 0x0000000f0000000full;
+    x = (x | (x << 14)) & 0x0003000300030003ull;
+    x = (x | (x << 7)) & 0x0101010101010101ull;
+    return x;
+}
+
+/* The command loop of yeast.c:1166-1295 as a flat state machine.  Every trip performs exactly
+ * one table lookup per stream (an insert-and-copy, literal or distance symbol, or the second
+ * level of a long code), so the streams that share a wavefront stay converged on the expensive
+ * part whatever mix of commands they are in.  The body is written as straight-line code with
+ * selects: in a wavefront of 64 streams every kind of trip occurs on every pass anyway, so
+ * branching around them would only add mask bookkeeping.  Window copies and dictionary words are
+ * validated and accounted for where they are decoded, but their bytes are moved later: they go to
+ * a short per-stream queue in LDS and the whole wavefront drains its queues together (the "second
+ * pass" that resolves LZ77 and dictionary references).
+ * SIMPLE: no block switching, one distance code (checked for the whole wavefront). */
+template <int G, bool SIMPLE>
+DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
+{
+    enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3, ACT_NONE = 4 };
+    Rd &r = c.r;
+    WaveLds<G> *wl = (WaveLds<G> *)c.wl;
+    const u32 slot = (threadIdx.x & 63) / G;
+    constexpr u32 S = 64 / G;
+    const bool ctx = fe.ctx;
+    const u64 *cmd_tab = c.sh->cmd;
+    u32 cur_mode = fe.cur_mode;
+    u32 st = ST_CMD;
+    u32 offI = gld32(fe.itab), offL = fe.offL0, offD = fe.offD0;
+    u32 off = offI;
+    u32 insert = 0, copy = 0, implicit = 0;
+    u32 link = 0;             /* root entry of a long code whose second lookup is this trip's work */
+    /* last two bytes of the newest copy: raw load results still in flight (nothing is computed
+       from them until the next lookup has returned), 1 = two bytes, 2 = one byte + pn_c */
+    u32 pn = 0, pn_c = 0, pn_valid = 0;
+    u8 *const mb_base = c.outp; /* queue entries hold offsets from here (mlen < 2^25) */
+    u32 qn = 0, pend_rel = 0, stale = 0;
+    /* max distance into the window = min(bytes produced so far, window size), kept incrementally */
+    u64 got0 = got_of(c);
+    u32 maxd = got0 > c.wsize ? c.wsize : (u32)got0;
+    const bool lds_lt = SIMPLE ? ctx : (ctx && c.L.num == 1);
+    if (lds_lt) { /* the 64 table offsets of the only literal block type move to LDS */
+        for (u32 n = sub; n < 64; n += G)
+            wl->lt[n * S + slot] = gld32(fe.lit_tab + n);
+    }
+    u32 nxt_empty = 0;
+    /* a refill in the middle of a trip: the prefetched word is in a register (pinned after the
+       lookup); no new load is started here, so the top of the next trip never waits */
+    auto refill_mid = [&]() {
+        if (r.have <= 32) {
+            if (nxt_empty) {
+                r.nxt = gld32(r.p + r.idx);
+                asm volatile("" : "+v"(r.nxt));
+            }
+            r.w |= (u64)r.nxt << r.have;
+            u32 add = r.rem < 32 ? r.rem : 32;
+            r.have += add;
+            r.rem -= add;
+            r.idx += add ? 1 : 0;
+            nxt_empty = 1;
+        }
+    };
+    auto next_lit_table = [&]() -> u32 {
+        u32 id = (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode);
+        if (SIMPLE)
+            return wl->lt[id * S + slot];
+        return lds_lt ? wl->lt[id * S + slot] : gld32(fe.lit_tab + id);
+    };
+    /* second pass over one stream's queue: one load round trip per entry */
+    auto drain = [&]() {
+        for (u32 k = 0; k < qn; k++) {
+            u32 qa = wl->qa[k * S + slot], qb = wl->qb[k * S + slot], qc = wl->qc[k * S + slot];
+            u8 *dst = mb_base + qa;
+            const u8 *src = dst - qc;
+            u32 len = qb, plen = 0, slen = 0, x32 = 0, x5 = 0;
+            u64 pre = 0, suf = 0;
+            bool slow = qc < qb || qb > 24; /* overlapping or long: the general copier */
+            if (qc >> 31) {
+                DictRef dr;
+                dict_prepare(c, (qc >> 26) & 31, qc & 0x3ffffu, dr);
+                if (dr.op == 1 || dr.op == 2)
+                    dict_masks(dr, x32, x5);
+                src = dr.w + dr.wskip;
+                len = dr.wlen;
+                plen = dr.plen;
+                slen = dr.slen;
+                pre = c.sh->xpre[dr.xform];
+                suf = c.sh->xsuf[dr.xform];
+                slow = false;
+            }
+            if (slow) {
+                copy_exact<G>(dst, qb, qc, sub);
+            } else {
+                u64 c0 = 0, c1 = 0, c2 = 0;
+                if (len)
+                    c0 = gld64u(src);
+                if (len > 8)
+                    c1 = gld64u(src + 8);
+                if (len > 16)
+                    c2 = gld64u(src + 16);
+                if (x32 | x5) {
+                    c0 ^= (spread8(x32) << 5) | (spread8(x5) * 5);
+                    c1 ^= (spread8(x32 >> 8) << 5) | (spread8(x5 >> 8) * 5);
+                    c2 ^= (spread8(x32 >> 16) << 5) | (spread8(x5 >> 16) * 5);
+                }
+                if (G == 1 || sub == 0) {
+                    u8 *wd = dst + plen;
+                    put_le(dst, pre, plen);
+                    put_le(wd, c0, len);
+                    if (len > 8)
+                        put_le(wd + 8, c1, len - 8);
+                    if (len > 16)
+                        put_le(wd + 16, c2, len - 16);
+                    put_le(wd + len, suf, slen);
+                }
+            }
+        }
+        qn = 0;
+    };
+    while (st != ST_END) {
+        if (!SIMPLE) {
+            if (!link) {
+                if (st == ST_CMD) {
+                    if (c.I.num > 1) {
+                        if (c.I.left == 0) {
+                            switch_block(c, c.I);
+                            offI = gld32(fe.itab + c.I.type);
+                        }
+                        c.I.left--;
+                    }
+                } else if (st == ST_LIT) {
+                    if (c.L.num > 1) {
+                        if (c.L.left == 0) {
+                            switch_block(c, c.L);
+                            cur_mode = gld8(fe.mode + c.L.type);
+                            if (ctx)
+                                offL = next_lit_table();
+                        }
+                        c.L.left--;
+                    }
+                } else {
+                    if (c.D.num > 1) {
+                        if (c.D.left == 0)
+                            switch_block(c, c.D);
+                        c.D.left--;
+                    }
+                    offD = fe.offD0;
+                    if (c.dist_codes > 1)
+                        offD = gld32(fe.dtab + (c.D.type << 2) + (copy > 4 ? 3 : copy - 2));
+                }
+            }
+        }
+        if (!link)
+            off = st == ST_CMD ? offI : st == ST_LIT ? offL : offD;
+
+        /* ---- the one table lookup of this trip ---- */
+        if (nxt_empty) { /* rare: a second refill in the previous trip used up the prefetched word */
+            r.nxt = gld32(r.p + r.idx);
+            asm volatile("" : "+v"(r.nxt));
+            nxt_empty = 0;
+        }
+        rd_refill(r); /* consumes a word that is in a register already; starts the next prefetch */
+        u32 peek = (u32)r.w;
+        u32 idx = link ? (link >> 4) + ((peek >> ROOT) & ((1u << ((link & 15) - ROOT)) - 1)) : (peek & 255);
+        u32 e = gld16((const u16 *)(c.ws + off) + idx);
+        /* what this trip does with the entry; ACT_NONE = first half of a long code, or failed */
+        u32 l = e & 15;
+        /* everything issued before the lookup has arrived with it: the prefetched input word
+           (pinned here so that the next refill finds it in a register, not in flight) and the
+           context bytes of the newest copy */
+        asm volatile("" : "+v"(r.nxt));
+        if (pn_valid) {
+            c.p1 = pn_valid == 1 ? pn >> 8 : pn_c;
+            c.p2 = pn & 255;
+            pn_valid = 0;
+        }
+        bool first_half = !link && l > ROOT;
+        link = first_half ? e : 0;
+        l = first_half ? 0 : l;
+        u32 act = first_half ? (u32)ACT_NONE : st;
+        if (l > r.have) {
+            rd_eof(r);
+            l = 0;
+            act = ACT_NONE;
+        }
+        r.w >>= l;
+        r.have -= l;
+        u32 sym = e >> 4;
+
+        /* ---- extra bits: insert + copy (command), distance extra, none (literal) ---- */
+        u64 ce = cmd_tab[sym < 704 ? sym : 0];
+        u32 iext = ((u32)ce >> 16) & 0xff, cext = (u32)(ce >> 40);
+        u32 dn = sym - c.direct - 16; /* distance symbols past the ring and direct codes */
+        bool dlong = act == ST_DIST && sym >= 16 + c.direct;
+        u32 dx = 1 + (dn >> (c.postfix + 1));
+        dx = dx > 25 ? 25 : dx; /* only after a read failure */
+        /* two fields at most: insert then copy extra bits, or the distance extra bits */
+        u32 n1 = act == ST_CMD ? iext : dlong ? dx : 0, n2 = act == ST_CMD ? cext : 0;
+        if (n1 > r.have)
+            refill_mid();
+        if (n1 > r.have) {
+            rd_eof(r);
+            n1 = n2 = 0;
+            act = ACT_NONE;
+        }
+        u32 x1 = (u32)r.w & ((1u << n1) - 1);
+        r.w >>= n1;
+        r.have -= n1;
+        if (n2 > r.have)
+            refill_mid();
+        if (n2 > r.have) {
+            rd_eof(r);
+            n2 = 0;
+            act = ACT_NONE;
+        }
+        u32 x2 = (u32)r.w & ((1u << n2) - 1);
+        r.w >>= n2;
+        r.have -= n2;
+
+        bool do_copy = false;
+        i64 dist = c.r0;
+        if (act == ST_CMD) {
+            insert = ((u32)ce & 0xffff) + x1;
+            copy = ((u32)(ce >> 24) & 0xffff) + x2;
+            if (insert > mlen) {
+                rd_fail(r, YS_INVALID); /* :1189 */
+                insert = 0;
+            }
+            mlen -= insert;
+            implicit = sym < 128;
+            st = insert ? (u32)ST_LIT : implicit ? (u32)ST_CMD : (u32)ST_DIST;
+            do_copy = !insert && implicit;
+        } else if (act == ST_LIT) {
+            gst8(c.outp, sym);
+            c.outp++;
+            maxd = maxd < c.wsize ? maxd + 1 : maxd;
+            c.p2 = c.p1;
+            c.p1 = sym;
+            if (--insert == 0) {
+                st = mlen == 0 ? (u32)ST_END : implicit ? (u32)ST_CMD : (u32)ST_DIST; /* :1227 */
+                do_copy = mlen != 0 && implicit;
+            }
+        } else if (act == ST_DIST) { /* distance(): yeast.c:761-789 */
+            u32 ds = sym;
+            if (ds < 16) {
+                u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
+                u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
+                u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
+                int dl = (int)(k >> 1) + 1;
+                dl = (k & 1) ? dl : -dl;
+                dl = ds < 4 ? 0 : dl;
+                dist = (i64)rv + dl;
+            } else if (!dlong)
+                dist = ds - 15;
+            else {
+                u64 o2 = ((u64)(2 + ((dn >> c.postfix) & 1)) << dx) - 4;
+                dist = (i64)(((o2 + x1) << c.postfix) + (dn & ((1u << c.postfix) - 1)) + c.direct + 1);
+            }
+            if (ds && dist > 0 && dist <= (i64)maxd) {
+                c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
+            }
+            do_copy = true;
+        }
+        if (do_copy && !r.rc) {
+            /* validate and account for the copy now; queue the byte moving */
+            u32 rel = (u32)(c.outp - mb_base), nout = 0, ref = 0;
+            if (dist <= 0) {
+                rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
+            } else if (dist > (i64)maxd) {
+                DictRef dr;
+                u64 id = (u64)dist - maxd - 1;
+                if (!dict_prepare(c, copy, id, dr) || dr.total > mlen) {
+                    rd_fail(r, YS_INVALID); /* :921-930, :1269 */
+                } else {
+                    nout = dr.total;
+                    ref = 0x80000000u | (u32)id | (copy << 26); /* id < 121 << 11 < 2^18 */
+                    if (ctx && nout) {
+                        /* last two bytes of the transformed word: suffix and prefix bytes are in
+                           LDS; raw dictionary bytes are fetched (arriving with the next lookup);
+                           the few cases that need the uppercase rules wait for the drain */
+                        if (dr.slen >= 2) {
+                            u64 sf = c.sh->xsuf[dr.xform] >> (8 * (dr.slen - 2));
+                            c.p2 = (u32)sf & 255;
+                            c.p1 = (u32)(sf >> 8) & 255;
+                            stale = 0;
+                        } else if (dr.wlen >= 2 + (1 - dr.slen) && dr.op != 2 && !(dr.op == 1 && dr.wlen < 5)) {
+                            const u8 *we = dr.w + dr.wskip + dr.wlen;
+                            if (dr.slen == 1) {
+                                pn_c = (u32)c.sh->xsuf[dr.xform] & 255;
+                                pn = gld8(we - 1);
+                                pn_valid = 2;
+                            } else {
+                                pn = gld16u(we - 2);
+                                pn_valid = 1;
+                            }
+                            stale = 0;
+                        } else
+                            stale = 1;
+                    }
+                }
+            } else if (copy > mlen) {
+                rd_fail(r, YS_INVALID); /* :1283 */
+            } else {
+                nout = copy;
+                ref = (u32)dist;
+                if (ctx) {
+                    /* the last two bytes of the copy, straight from its source when that
+                       is final already: not overlapping and not behind a queued write */
+                    u32 first = qn ? pend_rel : rel;
+                    if ((u32)dist >= copy && (i64)rel + copy - dist <= (i64)first) {
+                        const u8 *e2 = c.outp - dist + copy;
+                        pn = gld16u(e2 - 2);
+                        pn_valid = 1;
+                        stale = 0;
+                    } else
+                        stale = 1;
+                }
+            }
+            mlen -= nout;
+            if (nout) {
+                pend_rel = qn ? pend_rel : rel;
+                wl->qa[qn * S + slot] = rel;
+                wl->qb[qn * S + slot] = nout;
+                wl->qc[qn * S + slot] = ref;
+                qn++;
+            }
+            c.outp += nout;
+            u32 room = c.wsize - maxd;
+            maxd += nout < room ? nout : room;
+            st = mlen ? (u32)ST_CMD : (u32)ST_END;
+        }
+        st = r.rc ? (u32)ST_END : st;
+        /* second pass, the whole wavefront at once: when some queue is full or some
+           stream needs bytes that are still queued */
+        bool need = st == ST_LIT && ctx && stale;
+        if (__any(qn == FQ || need)) {
+#ifdef YS_PROFILE
+            u64 td0 = __builtin_readcyclecounter();
+#endif
+            drain();
+            if (need) {
+                group_sync_mem();
+                c.p1 = gld8(c.outp - 1);
+                c.p2 = gld8(c.outp - 2);
+                stale = 0;
+            }
+#ifdef YS_PROFILE
+            c.t_drain += __builtin_readcyclecounter() - td0;
+#endif
+        }
+        if (st == ST_LIT && ctx)
+            offL = next_lit_table();
+    }
+    /* metablock end (or failure): drain what is queued -- everything queued was valid */
+    drain();
+    if (pn_valid) {
+        c.p1 = pn_valid == 1 ? pn >> 8 : pn_c;
+        c.p2 = pn & 255;
+    }
+    if (stale && got_of(c) >= 2) { /* context for the next meta-block */
+        group_sync_mem();
+        c.p1 = gld8(c.outp - 1);
+        c.p2 = gld8(c.outp - 2);
+    }
+}
+
 /* ------------------------------------------------------------- meta-block */
 
 /* metablock(): yeast.c:971-1308.  Returns ISLAST. */
@@ -1159,6 +1546,9 @@ DEV u32 metablock(Ctx &c, u32 sub)
         return 1;
 
     /* ---- header: yeast.c:1078-1159 ---- */
+#ifdef YS_PROFILE
+    u64 tp0 = __builtin_readcyclecounter();
+#endif
     Hdr h;
     h.r = r;
     h.ws = c.ws;
@@ -1342,312 +1732,30 @@ DEV u32 metablock(Ctx &c, u32 sub)
             }
         } while (mlen && !r.rc);
     } else {
-        /* ---- the same command loop as a flat state machine: every trip performs exactly
-           one table lookup per stream (an insert-and-copy, literal or distance symbol, or the
-           second level of a long code), so the streams that share a wavefront stay converged
-           on the expensive part whatever mix of commands they are in.  Window copies and
-           dictionary words are validated and accounted for where they are decoded, but their
-           bytes are moved later: they go to a short per-stream queue in LDS and the whole
-           wavefront drains its queues together (the "second pass" that resolves LZ77 and
-           dictionary references).  yeast.c:1166-1295. ---- */
-        enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3 };
-        WaveLds<G> *wl = (WaveLds<G> *)c.wl;
-        const u32 slot = (threadIdx.x & 63) / G;
-        constexpr u32 S = 64 / G;
-        u32 st = ST_CMD;
-        u32 offI = gld32(itab), offL = (u32)((const u8 *)tL0 - c.ws), offD0 = (u32)((const u8 *)tD0 - c.ws);
-        u32 off = offI;
-        u32 insert = 0, copy = 0, implicit = 0;
-        u32 link = 0;   /* root entry of a long code whose second lookup is this trip's work */
-        u32 pn = 0, pn_valid = 0; /* last two bytes of the newest copy, loads still in flight */
-        u8 *const mb_base = c.outp; /* queue entries hold offsets from here (mlen < 2^25) */
-        u32 qn = 0, pend_rel = 0, stale = 0;
-        const bool lds_lt = ctx && c.L.num == 1;
-        if (lds_lt) { /* the 64 table offsets of the only literal block type move to LDS */
-            for (n = sub; n < 64; n += G)
-                wl->lt[n * S + slot] = gld32(lit_tab + n);
-        }
-        auto next_lit_table = [&]() -> u32 {
-            u32 id = (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode);
-            return lds_lt ? wl->lt[id * S + slot] : gld32(lit_tab + id);
-        };
-        /* second pass over one stream's queue: one load round trip per entry */
-        auto drain = [&]() {
-            for (u32 k = 0; k < qn; k++) {
-                u32 qa = wl->qa[k * S + slot], qb = wl->qb[k * S + slot], qc = wl->qc[k * S + slot];
-                u8 *dst = mb_base + qa;
-                const u8 *src;
-                u32 len, plen = 0, slen = 0, x32 = 0, x5 = 0;
-                u64 pre = 0, suf = 0;
-                bool slow;
-                if (qc >> 31) {
-                    DictRef dr;
-                    dict_prepare(c, (qc >> 26) & 31, qc & 0x3ffffu, dr);
-                    if (dr.op == 1 || dr.op == 2)
-                        dict_masks(dr, x32, x5);
-                    src = dr.w + dr.wskip;
-                    len = dr.wlen;
-                    plen = dr.plen;
-                    slen = dr.slen;
-                    pre = c.sh->xpre[dr.xform];
-                    suf = c.sh->xsuf[dr.xform];
-                    slow = false;
-                } else {
-                    src = dst - qc;
-                    len = qb;
-                    slow = qc < qb || qb > 24; /* overlapping or long: the general copier */
-                }
-                if (slow) {
-                    copy_exact<G>(dst, qb, qc, sub);
-                } else {
-                    u64 c0 = 0, c1 = 0, c2 = 0;
-                    if (len)
-                        c0 = gld64u(src);
-                    if (len > 8)
-                        c1 = gld64u(src + 8);
-                    if (len > 16)
-                        c2 = gld64u(src + 16);
-                    if (x32 | x5) {
-                        u64 m0 = 0, m1 = 0, m2 = 0;
-                        for (u32 j = 0; j < 8; j++) {
-                            m0 |= (u64)((((x32 >> j) & 1) << 5) | (((x5 >> j) & 1) * 5)) << (8 * j);
-                            m1 |= (u64)((((x32 >> (j + 8)) & 1) << 5) | (((x5 >> (j + 8)) & 1) * 5)) << (8 * j);
-                            m2 |= (u64)((((x32 >> (j + 16)) & 1) << 5) | (((x5 >> (j + 16)) & 1) * 5)) << (8 * j);
-                        }
-                        c0 ^= m0;
-                        c1 ^= m1;
-                        c2 ^= m2;
-                    }
-                    if (G == 1 || sub == 0) {
-                        u8 *wd = dst + plen;
-                        put_le(dst, pre, plen);
-                        put_le(wd, c0, len);
-                        if (len > 8)
-                            put_le(wd + 8, c1, len - 8);
-                        if (len > 16)
-                            put_le(wd + 16, c2, len - 16);
-                        put_le(wd + len, suf, slen);
-                    }
-                }
-            }
-            qn = 0;
-        };
-        while (st != ST_END) {
-            if (!link) {
-                if (st == ST_CMD) {
-                    if (c.I.num > 1) {
-                        if (c.I.left == 0) {
-                            switch_block(c, c.I);
-                            offI = gld32(itab + c.I.type);
-                        }
-                        c.I.left--;
-                    }
-                    off = offI;
-                } else if (st == ST_LIT) {
-                    if (c.L.num > 1) {
-                        if (c.L.left == 0) {
-                            switch_block(c, c.L);
-                            cur_mode = gld8(mode + c.L.type);
-                            if (ctx)
-                                offL = next_lit_table();
-                        }
-                        c.L.left--;
-                    }
-                    off = offL;
-                } else {
-                    if (c.D.num > 1) {
-                        if (c.D.left == 0)
-                            switch_block(c, c.D);
-                        c.D.left--;
-                    }
-                    off = offD0;
-                    if (c.dist_codes > 1)
-                        off = gld32(dtab + (c.D.type << 2) + (copy > 4 ? 3 : copy - 2));
-                }
-            }
-            /* the one table lookup of this trip */
-            rd_refill(r);
-            u32 peek = (u32)r.w;
-            u32 idx = link ? (link >> 4) + ((peek >> ROOT) & ((1u << ((link & 15) - ROOT)) - 1)) : (peek & 255);
-            u32 e = gld16((const u16 *)(c.ws + off) + idx);
-            if (pn_valid) { /* issued before the lookup above, so it has arrived with it */
-                c.p1 = pn >> 8;
-                c.p2 = pn & 255;
-                pn_valid = 0;
-            }
-            /* what this trip does with the entry: 4 = nothing yet (first half of a long code) */
-            u32 act = st;
-            u32 l = e & 15;
-            if (!link && l > ROOT) {
-                link = e;
-                act = 4;
-                l = 0;
-            } else
-                link = 0;
-            if (l > r.have) {
-                rd_eof(r);
-                l = 0;
-            }
-            r.w >>= l;
-            r.have -= l;
-            if (r.rc)
-                act = 4;
-            u32 sym = e >> 4;
-            bool do_copy = false;
-            i64 dist = 0;
-            if (act == ST_CMD) {
-                u64 ce = cmd_tab[sym < 704 ? sym : 0];
-                insert = ((u32)ce & 0xffff) + take(r, ((u32)ce >> 16) & 0xff);
-                copy = ((u32)(ce >> 24) & 0xffff) + take(r, (u32)(ce >> 40));
-                if (!r.rc && insert > mlen)
-                    rd_fail(r, YS_INVALID); /* :1189 */
-                mlen -= insert;
-                implicit = sym < 128;
-                if (insert)
-                    st = ST_LIT;
-                else if (implicit) {
-                    do_copy = true;
-                    dist = c.r0;
-                } else
-                    st = ST_DIST;
-            } else if (act == ST_LIT) {
-                gst8(c.outp, sym);
-                c.outp++;
-                c.p2 = c.p1;
-                c.p1 = sym;
-                if (--insert == 0) {
-                    if (mlen == 0)
-                        st = ST_END; /* the copy length is ignored :1227 */
-                    else if (implicit) {
-                        do_copy = true;
-                        dist = c.r0;
-                    } else
-                        st = ST_DIST;
-                }
-            } else if (act == ST_DIST) { /* distance(): yeast.c:761-789 */
-                u64 got = got_of(c);
-                u32 max = got > c.wsize ? c.wsize : (u32)got;
-                u32 ds = sym;
-                if (ds < 16) {
-                    u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
-                    u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
-                    int dl = 0;
-                    if (ds >= 4) {
-                        u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
-                        dl = (int)(k >> 1) + 1;
-                        if (!(k & 1))
-                            dl = -dl;
-                    }
-                    dist = (i64)rv + dl;
-                } else if (ds < 16 + c.direct)
-                    dist = ds - 15;
-                else {
-                    u32 nn = ds - c.direct - 16;
-                    u32 x = 1 + (nn >> (c.postfix + 1));
-                    if (x > 25)
-                        x = 25; /* only after a read failure */
-                    u64 o2 = ((u64)(2 + ((nn >> c.postfix) & 1)) << x) - 4;
-                    dist = (i64)(((o2 + take(r, x)) << c.postfix) + (nn & ((1u << c.postfix) - 1)) + c.direct + 1);
-                }
-                if (!r.rc && ds && dist > 0 && dist <= (i64)max) {
-                    c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
-                }
-                do_copy = true;
-            }
-            if (do_copy && !r.rc) {
-                /* validate and account for the copy now; queue the byte moving */
-                u64 got = got_of(c);
-                u32 max = got > c.wsize ? c.wsize : (u32)got;
-                u32 rel = (u32)(c.outp - mb_base), nout = 0, ref = 0;
-                if (dist <= 0) {
-                    rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
-                } else if (dist > (i64)max) {
-                    DictRef dr;
-                    u64 id = (u64)dist - max - 1;
-                    if (!dict_prepare(c, copy, id, dr) || dr.total > mlen) {
-                        rd_fail(r, YS_INVALID); /* :921-930, :1269 */
-                    } else {
-                        nout = dr.total;
-                        ref = 0x80000000u | (u32)id | (copy << 26); /* id < 121 << 11 < 2^18 */
-                        if (ctx && nout) {
-                            /* last two bytes of the transformed word: suffix and prefix bytes are in
-                               LDS; raw dictionary bytes are fetched (arriving with the next lookup);
-                               the few cases that need the uppercase rules wait for the drain */
-                            if (dr.slen >= 2) {
-                                u64 sf = c.sh->xsuf[dr.xform] >> (8 * (dr.slen - 2));
-                                c.p2 = (u32)sf & 255;
-                                c.p1 = (u32)(sf >> 8) & 255;
-                                stale = 0;
-                            } else if (dr.wlen >= 2 + (1 - dr.slen) && dr.op != 2 && !(dr.op == 1 && dr.wlen < 5)) {
-                                const u8 *we = dr.w + dr.wskip + dr.wlen;
-                                if (dr.slen == 1) {
-                                    pn = (((u32)c.sh->xsuf[dr.xform] & 255) << 8) | gld8(we - 1);
-                                } else
-                                    pn = (gld8(we - 1) << 8) | gld8(we - 2);
-                                pn_valid = 1;
-                                stale = 0;
-                            } else
-                                stale = 1;
-                        }
-                    }
-                } else if (copy > mlen) {
-                    rd_fail(r, YS_INVALID); /* :1283 */
-                } else {
-                    nout = copy;
-                    ref = (u32)dist;
-                    if (ctx) {
-                        /* the last two bytes of the copy, straight from its source when that
-                           is final already: not overlapping and not behind a queued write */
-                        u32 first = qn ? pend_rel : rel;
-                        if ((u32)dist >= copy && (i64)rel + copy - dist <= (i64)first) {
-                            const u8 *e2 = c.outp - dist + copy;
-                            pn = (gld8(e2 - 1) << 8) | gld8(e2 - 2);
-                            pn_valid = 1;
-                            stale = 0;
-                        } else
-                            stale = 1;
-                    }
-                }
-                mlen -= nout;
-                if (nout) {
-                    if (qn == 0)
-                        pend_rel = rel;
-                    wl->qa[qn * S + slot] = rel;
-                    wl->qb[qn * S + slot] = nout;
-                    wl->qc[qn * S + slot] = ref;
-                    qn++;
-                }
-                c.outp += nout;
-                st = mlen ? ST_CMD : ST_END;
-            }
-            if (r.rc)
-                st = ST_END;
-            /* second pass, the whole wavefront at once: when some queue is full or some
-               stream needs bytes that are still queued */
-            bool need = st == ST_LIT && ctx && stale;
-            if (__any(qn == FQ || need)) {
-                drain();
-                if (need) {
-                    group_sync_mem();
-                    c.p1 = gld8(c.outp - 1);
-                    c.p2 = gld8(c.outp - 2);
-                    stale = 0;
-                }
-            }
-            if (st == ST_LIT && ctx)
-                offL = next_lit_table();
-        }
-        /* metablock end (or failure): drain what is queued -- everything queued was valid */
-        drain();
-        if (pn_valid) {
-            c.p1 = pn >> 8;
-            c.p2 = pn & 255;
-        }
-        if (stale && got_of(c) >= 2) { /* context for the next meta-block */
-            group_sync_mem();
-            c.p1 = gld8(c.outp - 1);
-            c.p2 = gld8(c.outp - 2);
-        }
+#ifdef YS_PROFILE
+        u64 tp1 = __builtin_readcyclecounter();
+        c.t_hdr += tp1 - tp0;
+#endif
+        FlatEnv fe;
+        fe.itab = itab;
+        fe.dtab = dtab;
+        fe.lit_tab = lit_tab;
+        fe.mode = mode;
+        fe.offL0 = (u32)((const u8 *)tL0 - c.ws);
+        fe.offD0 = (u32)((const u8 *)tD0 - c.ws);
+        fe.cur_mode = cur_mode;
+        fe.ctx = ctx;
+        /* meta-blocks without block switching and with one distance code (the usual case for
+           short streams) run a loop that carries none of that machinery; the choice is made
+           for the whole wavefront so the streams stay in one loop */
+        bool simple = c.L.num == 1 && c.I.num == 1 && c.D.num == 1 && c.dist_codes == 1;
+        if (__all(simple))
+            run_flat<G, true>(c, mlen, sub, fe);
+        else
+            run_flat<G, false>(c, mlen, sub, fe);
+#ifdef YS_PROFILE
+        c.t_loop += __builtin_readcyclecounter() - tp1;
+#endif
     }
     if (!r.rc && last && tail_nonzero(r))
         rd_fail(r, YS_INVALID); /* :1305 */
@@ -1675,6 +1783,9 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     c.p1 = c.p2 = 0;
     c.nmeta = 0;
     c.need = 0;
+#ifdef YS_PROFILE
+    c.t_hdr = c.t_loop = c.t_drain = 0;
+#endif
     c.dict = p.dict;
     c.xf = p.xforms;
     c.sh = sh;
@@ -1713,6 +1824,9 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     /* bytes pulled: every byte when the bit reader ran dry, else ceil(bits/8) (yeast.c:1388) */
     rec.used = c.r.dry ? (s1 - s0) : (rd_pos(c.r) + 7) >> 3;
     rec.check = c.need;
+#ifdef YS_PROFILE
+    rec.check = ((c.t_hdr >> 10) & 0xfffff) | (((c.t_loop >> 10) & 0xfffff) << 20) | (((c.t_drain >> 10) & 0xfffff) << 40);
+#endif
     p.rec[job] = rec;
     if (c.r.rc == YS_WORKSPACE && !p.retry && sub == 0)
         p.retry_list[atomicAdd(p.retry_count, 1u)] = job;

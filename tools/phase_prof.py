@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Phase timing of the batch kernel (library built with -DYS_PROFILE): per-stream cycle counts of
+header parsing, command loop and queue drains, packed into record.check (check kind 0)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import helpers as H
+import brotli_amd as ba
+from brotli_amd.device import DeviceBatch
+meta, distinct = H.packed_streams("cfg2_streams")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+order = np.random.RandomState(3).randint(0, len(distinct), size=n)
+b = DeviceBatch([distinct[j] for j in order], [65536] * n)
+b.decode(check=0, lanes=lanes); torch.cuda.synchronize()
+b.decode(check=0, lanes=lanes); torch.cuda.synchronize()
+r = b.records()
+ck = r["check"]
+hdr = (ck & 0xfffff).astype(np.float64) * 1024
+loop = ((ck >> 20) & 0xfffff).astype(np.float64) * 1024
+drain = ((ck >> 40) & 0xfffff).astype(np.float64) * 1024
+print("rc ok:", (r["rc"] == 0).all())
+print("cycles/stream (constant 100 MHz counter?) mean: header %.0f  loop %.0f  of which drain %.0f" % (hdr.mean(), loop.mean(), drain.mean()))
+print("header share %.1f%%, drain share of loop %.1f%%" % (100 * hdr.mean() / (hdr.mean() + loop.mean()), 100 * drain.mean() / loop.mean()))
