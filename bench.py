@@ -36,8 +36,14 @@ def load_distinct():
     return meta["streams"], streams
 
 
-def build_order(n, ndistinct, seed):
-    """stream i of the batch = distinct[order[i]]: every distinct stream equally often, order permuted."""
+def build_order(n, ndistinct, seed, kind="shuffled"):
+    """stream i of the batch = distinct[order[i]]: every distinct stream equally often, order permuted.
+    kind "wave" (64 consecutive copies of one stream) and "same" (one stream only) are diagnostic
+    layouts that remove lane divergence; the bench line is always quoted on "shuffled"."""
+    if kind == "wave":
+        return (np.arange(n) // 64) % ndistinct
+    if kind == "same":
+        return np.zeros(n, dtype=np.int64)
     rng = np.random.RandomState(seed)
     reps = (n + ndistinct - 1) // ndistinct
     order = np.tile(np.arange(ndistinct), reps)[:n]
@@ -89,6 +95,8 @@ def main():
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (default: the cfg2 batch)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per stream (0 = library default)")
     ap.add_argument("--check", type=int, default=3, help="0 none, 1 crc32c, 2 xxh32, 3 xxh64")
+    ap.add_argument("--order", default="shuffled", choices=["shuffled", "wave", "same"],
+                    help="diagnostic stream layouts (see build_order); the metric is quoted on shuffled")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="streams for the host baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -111,7 +119,7 @@ def main():
 
     meta, distinct = load_distinct()
     n = args.streams
-    order = build_order(n, len(distinct), 0x5EED + rank)
+    order = build_order(n, len(distinct), 0x5EED + rank, args.order)
     streams = [distinct[j] for j in order]
     batch = DeviceBatch(streams, [65536] * n, device=dev)
     want_got = np.array([meta[j]["got"] for j in order], dtype=np.uint64)
@@ -200,7 +208,7 @@ def main():
                                "streams tiled in seeded order; decode + %s check%s"
                                % (n, len(distinct), {0: "no", 1: "CRC-32C", 2: "XXH32", 3: "XXH64"}[args.check],
                                   " + RCCL all-gather of records" if world > 1 else ""),
-                   "streams_per_gpu": n, "out_bytes_per_gpu": out_bytes, "in_bytes_per_gpu": in_bytes,
+                   "streams_per_gpu": n, "order": args.order, "out_bytes_per_gpu": out_bytes, "in_bytes_per_gpu": in_bytes,
                    "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "1")),
                    "parallelism": "%d independent shards" % world},
         "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": HBM_PEAK_GBS,

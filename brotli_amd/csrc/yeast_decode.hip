@@ -611,15 +611,61 @@ NOINL Hdr read_context_map(Hdr h, u8 *map, u32 len, u32 trees)
 
 /* ------------------------------------------------------------------ state */
 
-/* per-wavefront LDS of the batch kernel: the copy queues and the literal table map */
+/* per-wavefront LDS of the batch kernel: the copy queues, the literal table map and the output
+   staging rings.  Every array is [index][stream] so that the 64 streams of a wavefront touch 64
+   different banks whatever their indices are. */
 #define FQ 8
+#define RB 256        /* bytes of output staged per stream (the newest RB bytes of its output) */
+#define RU (RB / 8)   /* the ring is kept in 8-byte units */
+#define RB_SLACK 48   /* a drain is forced when fewer bytes than this are free */
 template <int G>
 struct WaveLds {
     u32 qa[FQ * 64 / G]; /* destination, bytes from the start of the meta-block's output */
-    u32 qb[FQ * 64 / G]; /* bytes to produce */
-    u32 qc[FQ * 64 / G]; /* distance, or bit 31 | word length << 26 | dictionary id */
-    u32 lt[64 * 64 / G]; /* [context][stream]: byte offset of the literal table */
+    u32 qb[FQ * 64 / G]; /* bytes to produce | kind << 28 */
+    u32 qc[FQ * 64 / G]; /* copy: distance; dictionary: transform << 25 | word bytes << 20 | word offset */
+    u16 lt[64 * 64 / G]; /* [context][stream]: byte offset of the literal table >> 4 */
+    u64 ring[RU * 64 / G]; /* [unit][stream] */
 };
+#define LAS __attribute__((address_space(3)))
+
+/* byte offset of output address a (low bits) in the ring array of a wavefront with S streams */
+template <int S>
+DEV u32 ring_at(u32 slot, u32 a) { return ((((a >> 3) & (RU - 1)) * S + slot) << 3) | (a & 7); }
+
+/* n (1..8) bytes of v to output address a, staged: a read-modify-write of the one or two units the
+   bytes fall in (bytes of v beyond n are ignored; neighbouring bytes in the units are kept) */
+template <int S>
+DEV void ring_put(LAS u8 *rb, u32 slot, u32 a, u64 v, u32 n)
+{
+    u32 s = (a & 7) * 8;
+    u64 m = n >= 8 ? ~0ull : ~(~0ull << (8 * n));
+    u32 u0 = (a >> 3) & (RU - 1), u1 = (u0 + 1) & (RU - 1);
+    LAS u64 *w0 = (LAS u64 *)(rb + ((u0 * S + slot) << 3));
+    u64 m0 = m << s;
+    *w0 = (*w0 & ~m0) | ((v << s) & m0);
+    u64 m1 = s ? m >> (64 - s) : 0;
+    if (m1) {
+        LAS u64 *w1 = (LAS u64 *)(rb + ((u1 * S + slot) << 3));
+        *w1 = (*w1 & ~m1) | ((v >> (64 - s)) & m1);
+    }
+}
+
+/* one complete 64-byte line from the ring to its place in the output region */
+template <int S>
+DEV void ring_flush_line(LAS u8 *rb, u32 slot, u8 *line)
+{
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    u32 u = ((u32)(u64)line >> 3) & (RU - 1);
+    u64 d[8];
+#pragma unroll
+    for (u32 j = 0; j < 8; j++)
+        d[j] = *(LAS u64 *)(rb + (((u + j) * S + slot) << 3));
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        u64x2 v = {d[2 * j], d[2 * j + 1]};
+        *(GAS u64x2 *)(line + 16 * j) = v;
+    }
+}
 
 struct Blk { /* one block category: yeast.c:112-123 */
     u32 num, type, prev, left;
@@ -1130,10 +1176,12 @@ template <int G, bool SIMPLE>
 DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
 {
     enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3, ACT_NONE = 4 };
+    enum { K_FAR = 0, K_BYTES = 1, K_SLOW = 2, K_DICT = 3 };
     Rd &r = c.r;
     WaveLds<G> *wl = (WaveLds<G> *)c.wl;
     const u32 slot = (threadIdx.x & 63) / G;
     constexpr u32 S = 64 / G;
+    LAS u8 *const rb = (LAS u8 *)wl->ring;
     const bool ctx = fe.ctx;
     const u64 *cmd_tab = c.sh->cmd;
     u32 cur_mode = fe.cur_mode;
@@ -1146,6 +1194,10 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
        from them until the next lookup has returned), 1 = two bytes, 2 = one byte + pn_c */
     u32 pn = 0, pn_c = 0, pn_valid = 0;
     u8 *const mb_base = c.outp; /* queue entries hold offsets from here (mlen < 2^25) */
+    /* Output is staged: bytes below fl are in the output region (final), bytes from fl up to
+       outp live in the ring -- literals at once, queued copies when the queue is drained.
+       outp - fl never exceeds RB. */
+    u8 *fl = c.outp;
     u32 qn = 0, pend_rel = 0, stale = 0;
     /* max distance into the window = min(bytes produced so far, window size), kept incrementally */
     u64 got0 = got_of(c);
@@ -1153,7 +1205,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
     const bool lds_lt = SIMPLE ? ctx : (ctx && c.L.num == 1);
     if (lds_lt) { /* the 64 table offsets of the only literal block type move to LDS */
         for (u32 n = sub; n < 64; n += G)
-            wl->lt[n * S + slot] = gld32(fe.lit_tab + n);
+            wl->lt[n * S + slot] = (u16)(gld32(fe.lit_tab + n) >> 4);
     }
     u32 nxt_empty = 0;
     /* a refill in the middle of a trip: the prefetched word is in a register (pinned after the
@@ -1175,59 +1227,154 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
     auto next_lit_table = [&]() -> u32 {
         u32 id = (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode);
         if (SIMPLE)
-            return wl->lt[id * S + slot];
-        return lds_lt ? wl->lt[id * S + slot] : gld32(fe.lit_tab + id);
+            return (u32)wl->lt[id * S + slot] << 4;
+        return lds_lt ? (u32)wl->lt[id * S + slot] << 4 : gld32(fe.lit_tab + id);
     };
-    /* second pass over one stream's queue: one load round trip per entry */
-    auto drain = [&]() {
-        for (u32 k = 0; k < qn; k++) {
-            u32 qa = wl->qa[k * S + slot], qb = wl->qb[k * S + slot], qc = wl->qc[k * S + slot];
-            u8 *dst = mb_base + qa;
-            const u8 *src = dst - qc;
-            u32 len = qb, plen = 0, slen = 0, x32 = 0, x5 = 0;
-            u64 pre = 0, suf = 0;
-            bool slow = qc < qb || qb > 24; /* overlapping or long: the general copier */
-            if (qc >> 31) {
-                DictRef dr;
-                dict_prepare(c, (qc >> 26) & 31, qc & 0x3ffffu, dr);
-                if (dr.op == 1 || dr.op == 2)
-                    dict_masks(dr, x32, x5);
-                src = dr.w + dr.wskip;
-                len = dr.wlen;
-                plen = dr.plen;
-                slen = dr.slen;
-                pre = c.sh->xpre[dr.xform];
-                suf = c.sh->xsuf[dr.xform];
-                slow = false;
+    auto staged = [&](const u8 *q) -> u32 { return rb[ring_at<S>(slot, (u32)(u64)q)]; };
+    /* ring -> output region: whole 64-byte lines below lim; exact: every byte below lim */
+    auto flush = [&](u8 *lim, bool exact) {
+        u8 *lim64 = exact ? lim : (u8 *)((u64)lim & ~63ull);
+        while (fl < lim64 && ((u64)fl & 63)) { /* ragged start: stream start, after a slow copy */
+            if (G == 1 || sub == 0)
+                gst8(fl, staged(fl));
+            fl++;
+        }
+        while (fl + 64 <= lim64) {
+            if (G == 1 || sub == 0)
+                ring_flush_line<S>(rb, slot, fl);
+            fl += 64;
+        }
+        if (exact)
+            while (fl < lim) {
+                if (G == 1 || sub == 0)
+                    gst8(fl, staged(fl));
+                fl++;
             }
-            if (slow) {
-                copy_exact<G>(dst, qb, qc, sub);
-            } else {
-                u64 c0 = 0, c1 = 0, c2 = 0;
-                if (len)
-                    c0 = gld64u(src);
-                if (len > 8)
-                    c1 = gld64u(src + 8);
-                if (len > 16)
-                    c2 = gld64u(src + 16);
-                if (x32 | x5) {
-                    c0 ^= (spread8(x32) << 5) | (spread8(x5) * 5);
-                    c1 ^= (spread8(x32 >> 8) << 5) | (spread8(x5 >> 8) * 5);
-                    c2 ^= (spread8(x32 >> 16) << 5) | (spread8(x5 >> 16) * 5);
-                }
-                if (G == 1 || sub == 0) {
-                    u8 *wd = dst + plen;
-                    put_le(dst, pre, plen);
-                    put_le(wd, c0, len);
+    };
+    /* the last two bytes of the output so far, when nothing is queued */
+    auto last_two = [&]() {
+        group_sync_mem(); /* bytes below fl are read back from the output region */
+        u64 got = got_of(c);
+        u32 b1 = 0, b2 = 0;
+        if (got >= 1)
+            b1 = c.outp - 1 >= fl ? staged(c.outp - 1) : gld8(c.outp - 1);
+        if (got >= 2)
+            b2 = c.outp - 2 >= fl ? staged(c.outp - 2) : gld8(c.outp - 2);
+        c.p1 = b1;
+        c.p2 = b2;
+    };
+    /* second pass over one stream's queue, entries in order, four source fetches per round trip */
+    constexpr u32 DB = 4;
+    auto drain = [&]() {
+        for (u32 k0 = 0; k0 < qn; k0 += DB) {
+            u32 ea[DB], eb[DB], ec[DB];
+            u64 d0[DB], d1[DB], d2[DB];
+#pragma unroll
+            for (u32 j = 0; j < DB; j++) {
+                u32 k = k0 + j;
+                ea[j] = eb[j] = ec[j] = 0;
+                d0[j] = d1[j] = d2[j] = 0;
+                if (k < qn) {
+                    ea[j] = wl->qa[k * S + slot];
+                    eb[j] = wl->qb[k * S + slot];
+                    ec[j] = wl->qc[k * S + slot];
+                    u32 kind = eb[j] >> 28, len = 0;
+                    const u8 *src = c.dict;
+                    if (kind == K_FAR) {
+                        src = mb_base + ea[j] - ec[j];
+                        len = eb[j] & 0xfffffffu;
+                    } else if (kind == K_DICT) {
+                        src = c.dict + (ec[j] & 0xfffffu);
+                        len = (ec[j] >> 20) & 31;
+                    }
+                    if (len)
+                        d0[j] = gld64u(src);
                     if (len > 8)
-                        put_le(wd + 8, c1, len - 8);
+                        d1[j] = gld64u(src + 8);
                     if (len > 16)
-                        put_le(wd + 16, c2, len - 16);
-                    put_le(wd + len, suf, slen);
+                        d2[j] = gld64u(src + 16);
+                }
+            }
+#pragma unroll
+            for (u32 j = 0; j < DB; j++) {
+                u32 k = k0 + j;
+                if (k < qn) {
+                    u32 kind = eb[j] >> 28, n = eb[j] & 0xfffffffu;
+                    u8 *dst = mb_base + ea[j];
+                    u32 a = (u32)(u64)dst;
+                    if (kind == K_FAR || kind == K_DICT) {
+                        u32 plen = 0, slen = 0, len = n;
+                        u64 pre = 0, suf = 0, w0 = d0[j], w1 = d1[j], w2 = d2[j];
+                        if (kind == K_DICT) {
+                            u32 xform = ec[j] >> 25;
+                            u32 hdr = c.sh->xf[xform], op = hdr & 255;
+                            plen = (hdr >> 16) & 255;
+                            slen = hdr >> 24;
+                            len = (ec[j] >> 20) & 31;
+                            pre = c.sh->xpre[xform];
+                            suf = c.sh->xsuf[xform];
+                            if (op == 1 || op == 2) { /* UPPER(): yeast.c:809-827, on the fetched word */
+                                u32 x32 = 0, x5 = 0, i = 0;
+                                do {
+                                    u64 w = i < 8 ? w0 : i < 16 ? w1 : w2;
+                                    u32 ch = (u32)(w >> (8 * (i & 7))) & 255;
+                                    if (ch < 192) {
+                                        if (ch >= 97 && ch <= 122)
+                                            x32 |= 1u << i;
+                                        i += 1;
+                                    } else if (ch < 224) {
+                                        if (i + 1 < len)
+                                            x32 |= 1u << (i + 1);
+                                        i += 2;
+                                    } else {
+                                        if (i + 2 < len)
+                                            x5 |= 1u << (i + 2);
+                                        i += 3;
+                                    }
+                                } while (op == 2 && i < len);
+                                w0 ^= (spread8(x32) << 5) | (spread8(x5) * 5);
+                                w1 ^= (spread8(x32 >> 8) << 5) | (spread8(x5 >> 8) * 5);
+                                w2 ^= (spread8(x32 >> 16) << 5) | (spread8(x5 >> 16) * 5);
+                            }
+                        }
+                        if (plen)
+                            ring_put<S>(rb, slot, a, pre, plen);
+                        a += plen;
+                        if (len)
+                            ring_put<S>(rb, slot, a, w0, len);
+                        if (len > 8)
+                            ring_put<S>(rb, slot, a + 8, w1, len - 8);
+                        if (len > 16)
+                            ring_put<S>(rb, slot, a + 16, w2, len - 16);
+                        if (len > 24) { /* a long copy that fits the ring (never a dictionary word) */
+                            const u8 *src = dst - ec[j];
+                            for (u32 i = 24; i < len; i += 8)
+                                ring_put<S>(rb, slot, a + i, gld64u(src + i), len - i);
+                        }
+                        if (slen)
+                            ring_put<S>(rb, slot, a + len, suf, slen);
+                    } else if (kind == K_BYTES) {
+                        /* near or overlapping copy: byte-serial (yeast.c:1285-1293), each source byte
+                           from wherever it is now */
+                        const u8 *src = dst - ec[j];
+                        for (u32 i = 0; i < n; i++) {
+                            u32 b = src + i < fl ? gld8(src + i) : staged(src + i);
+                            rb[ring_at<S>(slot, a + i)] = (u8)b;
+                        }
+                    } else {
+                        /* too long for the ring: bring the output region up to date and copy there;
+                           this is always the newest entry and the drain follows it at once */
+                        flush(dst, true);
+                        group_sync_mem();
+                        copy_exact<G>(dst, n, ec[j], sub);
+                        group_sync_mem();
+                        fl = dst + n;
+                    }
                 }
             }
         }
         qn = 0;
+        flush(c.outp, false);
     };
     while (st != ST_END) {
         if (!SIMPLE) {
@@ -1343,7 +1490,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             st = insert ? (u32)ST_LIT : implicit ? (u32)ST_CMD : (u32)ST_DIST;
             do_copy = !insert && implicit;
         } else if (act == ST_LIT) {
-            gst8(c.outp, sym);
+            rb[ring_at<S>(slot, (u32)(u64)c.outp)] = (u8)sym;
             c.outp++;
             maxd = maxd < c.wsize ? maxd + 1 : maxd;
             c.p2 = c.p1;
@@ -1375,7 +1522,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         }
         if (do_copy && !r.rc) {
             /* validate and account for the copy now; queue the byte moving */
-            u32 rel = (u32)(c.outp - mb_base), nout = 0, ref = 0;
+            u32 rel = (u32)(c.outp - mb_base), nout = 0, ref = 0, kind = K_FAR;
             if (dist <= 0) {
                 rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
             } else if (dist > (i64)maxd) {
@@ -1385,7 +1532,8 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
                     rd_fail(r, YS_INVALID); /* :921-930, :1269 */
                 } else {
                     nout = dr.total;
-                    ref = 0x80000000u | (u32)id | (copy << 26); /* id < 121 << 11 < 2^18 */
+                    kind = K_DICT;
+                    ref = (dr.xform << 25) | (dr.wlen << 20) | (u32)(dr.w + dr.wskip - c.dict);
                     if (ctx && nout) {
                         /* last two bytes of the transformed word: suffix and prefix bytes are in
                            LDS; raw dictionary bytes are fetched (arriving with the next lookup);
@@ -1415,14 +1563,21 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             } else {
                 nout = copy;
                 ref = (u32)dist;
+                const u8 *s1 = c.outp - dist + copy; /* end of the source */
+                bool fits = (u32)(c.outp - fl) + copy <= RB;
+                kind = !fits ? (u32)K_SLOW : s1 <= fl ? (u32)K_FAR : (u32)K_BYTES;
                 if (ctx) {
-                    /* the last two bytes of the copy, straight from its source when that
-                       is final already: not overlapping and not behind a queued write */
-                    u32 first = qn ? pend_rel : rel;
-                    if ((u32)dist >= copy && (i64)rel + copy - dist <= (i64)first) {
-                        const u8 *e2 = c.outp - dist + copy;
-                        pn = gld16u(e2 - 2);
+                    /* the last two bytes of the copy, straight from its source when that is
+                       final already: in the output region (fetched, arriving with the next
+                       lookup) or staged and not behind a queued write */
+                    const u8 *first = qn ? mb_base + pend_rel : c.outp;
+                    if (s1 <= fl) {
+                        pn = gld16u(s1 - 2);
                         pn_valid = 1;
+                        stale = 0;
+                    } else if ((u32)dist >= copy && s1 - 2 >= fl && s1 <= first) {
+                        c.p1 = staged(s1 - 1);
+                        c.p2 = staged(s1 - 2);
                         stale = 0;
                     } else
                         stale = 1;
@@ -1432,7 +1587,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             if (nout) {
                 pend_rel = qn ? pend_rel : rel;
                 wl->qa[qn * S + slot] = rel;
-                wl->qb[qn * S + slot] = nout;
+                wl->qb[qn * S + slot] = nout | (kind << 28);
                 wl->qc[qn * S + slot] = ref;
                 qn++;
             }
@@ -1442,18 +1597,16 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             st = mlen ? (u32)ST_CMD : (u32)ST_END;
         }
         st = r.rc ? (u32)ST_END : st;
-        /* second pass, the whole wavefront at once: when some queue is full or some
-           stream needs bytes that are still queued */
+        /* second pass, the whole wavefront at once: when some queue is full, some ring is nearly
+           full, or some stream needs bytes that are still queued */
         bool need = st == ST_LIT && ctx && stale;
-        if (__any(qn == FQ || need)) {
+        if (__any(qn == FQ || need || (u64)(c.outp - fl) > RB - RB_SLACK)) {
 #ifdef YS_PROFILE
             u64 td0 = __builtin_readcyclecounter();
 #endif
             drain();
             if (need) {
-                group_sync_mem();
-                c.p1 = gld8(c.outp - 1);
-                c.p2 = gld8(c.outp - 2);
+                last_two();
                 stale = 0;
             }
 #ifdef YS_PROFILE
@@ -1463,17 +1616,17 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         if (st == ST_LIT && ctx)
             offL = next_lit_table();
     }
-    /* metablock end (or failure): drain what is queued -- everything queued was valid */
+    /* metablock end (or failure): drain what is queued -- everything queued was valid -- and
+       bring the output region up to date */
     drain();
+    flush(c.outp, true);
+    group_sync_mem();
     if (pn_valid) {
         c.p1 = pn_valid == 1 ? pn >> 8 : pn_c;
         c.p2 = pn & 255;
     }
-    if (stale && got_of(c) >= 2) { /* context for the next meta-block */
-        group_sync_mem();
-        c.p1 = gld8(c.outp - 1);
-        c.p2 = gld8(c.outp - 2);
-    }
+    if (stale) /* context for the next meta-block */
+        last_two();
 }
 
 /* ------------------------------------------------------------- meta-block */

@@ -236,6 +236,8 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     u64 stride = (u64)env_int("YEAST_WS_KB", 48) * 1024;
     if (stride < YS_WS_ARENA + 8192)
         stride = YS_WS_ARENA + 8192;
+    if (flat && stride > (1u << 20))
+        stride = 1u << 20; /* the batch kernel keeps table offsets >> 4 in 16 bits */
     if (grow(d.ws, (size_t)groups * stride))
         return -1;
     /* counters: [0] main queue head, [1] retry queue head, [2] retry count; then the retry list */
