@@ -19,7 +19,8 @@ import os
 from typing import List, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyeast_mi355x.so")
+# YEAST_LIB selects another build of the same library (tools/phase_prof.py uses an instrumented one)
+LIB_PATH = os.environ.get("YEAST_LIB") or os.path.join(_HERE, "libyeast_mi355x.so")
 
 CHECK_NONE, CHECK_CRC32C, CHECK_XXH32, CHECK_XXH64 = 0, 1, 2, 3
 SRC_PAD = 32

@@ -615,16 +615,19 @@ NOINL Hdr read_context_map(Hdr h, u8 *map, u32 len, u32 trees)
    staging rings.  Every array is [index][stream] so that the 64 streams of a wavefront touch 64
    different banks whatever their indices are. */
 #define FQ 8
+#ifndef YS_HOLD
+#define YS_HOLD 12 /* trips a literal may wait for its context bytes before a drain is forced */
+#endif
 #define RB 256        /* bytes of output staged per stream (the newest RB bytes of its output) */
 #define RU (RB / 8)   /* the ring is kept in 8-byte units */
 #define RB_SLACK 48   /* a drain is forced when fewer bytes than this are free */
-template <int G>
+template <int S> /* S streams share the wavefront */
 struct WaveLds {
-    u32 qa[FQ * 64 / G]; /* destination, bytes from the start of the meta-block's output */
-    u32 qb[FQ * 64 / G]; /* bytes to produce | kind << 28 */
-    u32 qc[FQ * 64 / G]; /* copy: distance; dictionary: transform << 25 | word bytes << 20 | word offset */
-    u16 lt[64 * 64 / G]; /* [context][stream]: byte offset of the literal table >> 4 */
-    u64 ring[RU * 64 / G]; /* [unit][stream] */
+    u32 qa[FQ * S]; /* destination, bytes from the start of the meta-block's output */
+    u32 qb[FQ * S]; /* bytes to produce | kind << 28 */
+    u32 qc[FQ * S]; /* copy: distance; dictionary: transform << 25 | word bytes << 20 | word offset */
+    u16 lt[64 * S]; /* [context][stream]: byte offset of the literal table >> 4 */
+    u64 ring[RU * S]; /* [unit][stream] */
 };
 #define LAS __attribute__((address_space(3)))
 
@@ -648,6 +651,16 @@ DEV void ring_put(LAS u8 *rb, u32 slot, u32 a, u64 v, u32 n)
         LAS u64 *w1 = (LAS u64 *)(rb + ((u1 * S + slot) << 3));
         *w1 = (*w1 & ~m1) | ((v >> (64 - s)) & m1);
     }
+}
+
+/* the 8 staged bytes from output address a on */
+template <int S>
+DEV u64 ring_get(LAS u8 *rb, u32 slot, u32 a)
+{
+    u32 s = (a & 7) * 8;
+    u32 u0 = (a >> 3) & (RU - 1), u1 = (u0 + 1) & (RU - 1);
+    u64 w0 = *(LAS u64 *)(rb + ((u0 * S + slot) << 3)), w1 = *(LAS u64 *)(rb + ((u1 * S + slot) << 3));
+    return s ? (w0 >> s) | (w1 << (64 - s)) : w0;
 }
 
 /* one complete 64-byte line from the ring to its place in the output region */
@@ -690,9 +703,10 @@ struct Ctx {
     u64 need; /* output bytes required when rc == YS_CAPACITY */
     const u8 *dict, *xf;
     const Shared *sh;
-    void *wl; /* WaveLds<G> of this wavefront (batch kernel only) */
+    void *wl; /* WaveLds<S> of this wavefront (batch kernel only) */
 #ifdef YS_PROFILE
-    u64 t_hdr, t_loop, t_drain;
+    u64 t_hdr, t_loop, t_drain, t_look, t_dload;
+    u32 n_trips, n_drains, n_need, n_qfull, n_rfull, n_ents;
 #endif
 };
 
@@ -1172,15 +1186,14 @@ DEV u64 spread8(u32 b)
  * a short per-stream queue in LDS and the whole wavefront drains its queues together (the "second
  * pass" that resolves LZ77 and dictionary references).
  * SIMPLE: no block switching, one distance code (checked for the whole wavefront). */
-template <int G, bool SIMPLE>
+template <int G, int S, bool SIMPLE>
 DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
 {
     enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3, ACT_NONE = 4 };
     enum { K_FAR = 0, K_BYTES = 1, K_SLOW = 2, K_DICT = 3 };
     Rd &r = c.r;
-    WaveLds<G> *wl = (WaveLds<G> *)c.wl;
+    WaveLds<S> *wl = (WaveLds<S> *)c.wl;
     const u32 slot = (threadIdx.x & 63) / G;
-    constexpr u32 S = 64 / G;
     LAS u8 *const rb = (LAS u8 *)wl->ring;
     const bool ctx = fe.ctx;
     const u64 *cmd_tab = c.sh->cmd;
@@ -1198,7 +1211,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
        outp live in the ring -- literals at once, queued copies when the queue is drained.
        outp - fl never exceeds RB. */
     u8 *fl = c.outp;
-    u32 qn = 0, pend_rel = 0, stale = 0;
+    u32 qn = 0, pend_rel = 0, stale = 0, held = 0;
     /* max distance into the window = min(bytes produced so far, window size), kept incrementally */
     u64 got0 = got_of(c);
     u32 maxd = got0 > c.wsize ? c.wsize : (u32)got0;
@@ -1269,6 +1282,9 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         for (u32 k0 = 0; k0 < qn; k0 += DB) {
             u32 ea[DB], eb[DB], ec[DB];
             u64 d0[DB], d1[DB], d2[DB];
+#ifdef YS_PROFILE
+            u64 tb0 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
             for (u32 j = 0; j < DB; j++) {
                 u32 k = k0 + j;
@@ -1295,6 +1311,10 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
                         d2[j] = gld64u(src + 16);
                 }
             }
+#ifdef YS_PROFILE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            c.t_dload += __builtin_readcyclecounter() - tb0;
+#endif
 #pragma unroll
             for (u32 j = 0; j < DB; j++) {
                 u32 k = k0 + j;
@@ -1315,6 +1335,9 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
                             suf = c.sh->xsuf[xform];
                             if (op == 1 || op == 2) { /* UPPER(): yeast.c:809-827, on the fetched word */
                                 u32 x32 = 0, x5 = 0, i = 0;
+#ifdef YS_PROFILE
+                                c.n_rfull++;
+#endif
                                 do {
                                     u64 w = i < 8 ? w0 : i < 16 ? w1 : w2;
                                     u32 ch = (u32)(w >> (8 * (i & 7))) & 255;
@@ -1354,12 +1377,38 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
                         if (slen)
                             ring_put<S>(rb, slot, a + len, suf, slen);
                     } else if (kind == K_BYTES) {
-                        /* near or overlapping copy: byte-serial (yeast.c:1285-1293), each source byte
-                           from wherever it is now */
-                        const u8 *src = dst - ec[j];
-                        for (u32 i = 0; i < n; i++) {
-                            u32 b = src + i < fl ? gld8(src + i) : staged(src + i);
-                            rb[ring_at<S>(slot, a + i)] = (u8)b;
+                        /* near or overlapping copy (byte-serial in yeast.c:1285-1293): 8 bytes at a
+                           time, each group from wherever its source is now.  A distance below 8 is
+                           a repeating pattern: its first 8 bytes are built in a register, and from
+                           there on the same bytes are found a multiple of the distance back. */
+                        u32 d = ec[j], i = 0;
+                        if (d < 8) {
+                            const u8 *src = dst - d;
+                            u64 pat = 0;
+                            if (src >= fl)
+                                pat = ring_get<S>(rb, slot, (u32)(u64)src) & ~(~0ull << (8 * d));
+                            else
+                                for (u32 b = 0; b < d; b++)
+                                    pat |= (u64)(src + b < fl ? gld8(src + b) : staged(src + b)) << (8 * b);
+                            for (u32 w = d; w < 8; w <<= 1)
+                                pat |= pat << (8 * w);
+                            ring_put<S>(rb, slot, a, pat, n);
+                            d *= d >= 4 ? 2 : d == 3 ? 3 : d == 2 ? 4 : 8;
+                            i = 8;
+                        }
+                        for (; i < n; i += 8) {
+                            const u8 *src = dst + i - d;
+                            u64 v;
+                            if (src >= fl)
+                                v = ring_get<S>(rb, slot, (u32)(u64)src);
+                            else if (src + 8 <= fl)
+                                v = gld64u(src);
+                            else {
+                                v = 0;
+                                for (u32 b = 0; b < 8; b++)
+                                    v |= (u64)(src + b < fl ? gld8(src + b) : staged(src + b)) << (8 * b);
+                            }
+                            ring_put<S>(rb, slot, a + i, v, n - i);
                         }
                     } else {
                         /* too long for the ring: bring the output region up to date and copy there;
@@ -1377,8 +1426,10 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         flush(c.outp, false);
     };
     while (st != ST_END) {
+        /* a literal whose context bytes are still queued waits for the next drain */
+        const bool hold = st == ST_LIT && ctx && stale;
         if (!SIMPLE) {
-            if (!link) {
+            if (!link && !hold) {
                 if (st == ST_CMD) {
                     if (c.I.num > 1) {
                         if (c.I.left == 0) {
@@ -1421,7 +1472,15 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         rd_refill(r); /* consumes a word that is in a register already; starts the next prefetch */
         u32 peek = (u32)r.w;
         u32 idx = link ? (link >> 4) + ((peek >> ROOT) & ((1u << ((link & 15) - ROOT)) - 1)) : (peek & 255);
+#ifdef YS_PROFILE
+        u64 tl0 = __builtin_readcyclecounter();
+#endif
         u32 e = gld16((const u16 *)(c.ws + off) + idx);
+#ifdef YS_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(e));
+        c.t_look += __builtin_readcyclecounter() - tl0;
+        c.n_trips++;
+#endif
         /* what this trip does with the entry; ACT_NONE = first half of a long code, or failed */
         u32 l = e & 15;
         /* everything issued before the lookup has arrived with it: the prefetched input word
@@ -1434,9 +1493,10 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             pn_valid = 0;
         }
         bool first_half = !link && l > ROOT;
+        first_half = first_half && !hold;
         link = first_half ? e : 0;
-        l = first_half ? 0 : l;
-        u32 act = first_half ? (u32)ACT_NONE : st;
+        l = first_half || hold ? 0 : l;
+        u32 act = first_half || hold ? (u32)ACT_NONE : st;
         if (l > r.have) {
             rd_eof(r);
             l = 0;
@@ -1567,20 +1627,27 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
                 bool fits = (u32)(c.outp - fl) + copy <= RB;
                 kind = !fits ? (u32)K_SLOW : s1 <= fl ? (u32)K_FAR : (u32)K_BYTES;
                 if (ctx) {
-                    /* the last two bytes of the copy, straight from its source when that is
-                       final already: in the output region (fetched, arriving with the next
-                       lookup) or staged and not behind a queued write */
+                    /* the last two bytes of the copy, straight from their sources when those are
+                       final already (not behind a queued write): fetched from the output region
+                       (arriving with the next lookup) or read from the ring */
                     const u8 *first = qn ? mb_base + pend_rel : c.outp;
-                    if (s1 <= fl) {
-                        pn = gld16u(s1 - 2);
+                    u32 i1 = copy - 1, i2 = copy - 2;
+                    if ((u32)dist < copy) { /* overlapping: byte i repeats byte i mod dist */
+                        i1 %= (u32)dist;
+                        i2 %= (u32)dist;
+                    }
+                    const u8 *q1 = c.outp - dist + i1, *q2 = c.outp - dist + i2;
+                    if (q1 >= first || q2 >= first)
+                        stale = 1;
+                    else if (q2 + 1 == q1 && q1 < fl) {
+                        pn = gld16u(q2);
                         pn_valid = 1;
                         stale = 0;
-                    } else if ((u32)dist >= copy && s1 - 2 >= fl && s1 <= first) {
-                        c.p1 = staged(s1 - 1);
-                        c.p2 = staged(s1 - 2);
+                    } else {
+                        c.p1 = q1 >= fl ? staged(q1) : gld8(q1);
+                        c.p2 = q2 >= fl ? staged(q2) : gld8(q2);
                         stale = 0;
-                    } else
-                        stale = 1;
+                    }
                 }
             }
             mlen -= nout;
@@ -1600,17 +1667,22 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         /* second pass, the whole wavefront at once: when some queue is full, some ring is nearly
            full, or some stream needs bytes that are still queued */
         bool need = st == ST_LIT && ctx && stale;
-        if (__any(qn == FQ || need || (u64)(c.outp - fl) > RB - RB_SLACK)) {
+        held = need ? held + 1 : 0;
+        if (__any(qn == FQ || held > YS_HOLD || (u64)(c.outp - fl) > RB - RB_SLACK)) {
 #ifdef YS_PROFILE
             u64 td0 = __builtin_readcyclecounter();
+            c.n_need += need;
+            c.n_qfull += qn == FQ;
 #endif
             drain();
             if (need) {
                 last_two();
                 stale = 0;
+                held = 0;
             }
 #ifdef YS_PROFILE
             c.t_drain += __builtin_readcyclecounter() - td0;
+            c.n_drains++;
 #endif
         }
         if (st == ST_LIT && ctx)
@@ -1632,7 +1704,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
 /* ------------------------------------------------------------- meta-block */
 
 /* metablock(): yeast.c:971-1308.  Returns ISLAST. */
-template <int G, bool CMP, bool FLAT>
+template <int G, bool CMP, int FLAT> /* FLAT: 0, or the streams per wavefront of the batch kernel */
 DEV u32 metablock(Ctx &c, u32 sub)
 {
     Rd &r = c.r;
@@ -1903,9 +1975,9 @@ DEV u32 metablock(Ctx &c, u32 sub)
            for the whole wavefront so the streams stay in one loop */
         bool simple = c.L.num == 1 && c.I.num == 1 && c.D.num == 1 && c.dist_codes == 1;
         if (__all(simple))
-            run_flat<G, true>(c, mlen, sub, fe);
+            run_flat<G, FLAT ? FLAT : 64, true>(c, mlen, sub, fe);
         else
-            run_flat<G, false>(c, mlen, sub, fe);
+            run_flat<G, FLAT ? FLAT : 64, false>(c, mlen, sub, fe);
 #ifdef YS_PROFILE
         c.t_loop += __builtin_readcyclecounter() - tp1;
 #endif
@@ -1916,7 +1988,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
 }
 
 /* yeast(): yeast.c:1353-1400 for one stream of the batch */
-template <int G, bool CMP, bool FLAT>
+template <int G, bool CMP, int FLAT>
 DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub, void *wl = nullptr)
 {
     Ctx c;
@@ -1937,7 +2009,8 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     c.nmeta = 0;
     c.need = 0;
 #ifdef YS_PROFILE
-    c.t_hdr = c.t_loop = c.t_drain = 0;
+    c.t_hdr = c.t_loop = c.t_drain = c.t_look = c.t_dload = 0;
+    c.n_trips = c.n_drains = c.n_need = c.n_qfull = c.n_rfull = c.n_ents = 0;
 #endif
     c.dict = p.dict;
     c.xf = p.xforms;
@@ -1979,6 +2052,9 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     rec.check = c.need;
 #ifdef YS_PROFILE
     rec.check = ((c.t_hdr >> 10) & 0xfffff) | (((c.t_loop >> 10) & 0xfffff) << 20) | (((c.t_drain >> 10) & 0xfffff) << 40);
+    rec.used = (c.t_look >> 10) | ((u64)c.n_trips << 32);
+    rec.flags = c.n_drains;
+    rec.got = (u64)(c.n_need & 0xfff) | ((u64)(c.n_qfull & 0xfff) << 12) | ((u64)(c.n_rfull & 0xfff) << 24) | ((c.t_dload >> 10) << 36);
 #endif
     p.rec[job] = rec;
     if (c.r.rc == YS_WORKSPACE && !p.retry && sub == 0)
@@ -2004,37 +2080,39 @@ __global__ __launch_bounds__(256, YS_MIN_WAVES) void k_decode(ys_params p)
             break;
         if (p.retry)
             job = p.retry_list[job];
-        decode_stream<G, CMP, false>(p, job, ws, &sh, sub);
+        decode_stream<G, CMP, 0>(p, job, ws, &sh, sub);
     }
 }
 
 /* Batch kernel: every group of a wavefront starts its stream at the same time, so header
-   parsing, the flat command loop and the record write-out run converged across the
-   64 / G streams of the wavefront; a wavefront takes the next 64 / G streams when all
-   of its groups are done. */
-template <int G>
-__global__ __launch_bounds__(256, 1) void k_decode_flat(ys_params p)
+   parsing, the flat command loop and the record write-out run converged across the S streams
+   of the wavefront; a wavefront takes the next S streams when all of its groups are done.
+   S * G = 64 fills the wavefront; S * G = 32 leaves the upper half idle so that two wavefronts
+   fit each SIMD and one's instruction and memory latency hides behind the other's work. */
+template <int G, int S>
+__global__ __launch_bounds__(256, 64 / (S * G)) void k_decode_flat(ys_params p)
 {
     __shared__ Shared sh;
-    __shared__ WaveLds<G> wlds[4];
+    __shared__ WaveLds<S> wlds[4];
     shared_fill(sh, p.xforms);
     u32 lane = threadIdx.x;
     u32 sub = lane & (G - 1);
-    u32 gid = (blockIdx.x * blockDim.x + lane) / G;
-    u8 *ws = p.ws + (u64)gid * p.ws_stride;
+    u32 wave = (blockIdx.x * blockDim.x + lane) >> 6;
+    u32 slot = (lane & 63) / G;
+    u8 *ws = p.ws + (u64)(wave * S + (slot < S ? slot : 0)) * p.ws_stride;
     const u32 limit = p.retry ? *p.retry_count : p.n;
     for (;;) {
         u32 base = 0;
         if ((lane & 63) == 0)
-            base = atomicAdd(p.counter, 64u / G);
+            base = atomicAdd(p.counter, (u32)S);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= limit)
             break;
-        u32 job = base + (lane & 63) / G;
-        if (job < limit) {
+        u32 job = base + slot;
+        if (slot < S && job < limit) {
             if (p.retry)
                 job = p.retry_list[job];
-            decode_stream<G, false, true>(p, job, ws, &sh, sub, &wlds[lane >> 6]);
+            decode_stream<G, false, S>(p, job, ws, &sh, sub, &wlds[lane >> 6]);
         }
     }
 }
@@ -2105,23 +2183,23 @@ extern "C" int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cm
     return -1;
 }
 
-template <int G>
+template <int G, int S>
 static int launch_flat_t(const ys_params &p, u32 groups, hipStream_t st)
 {
-    u32 per_block = 256 / G;
+    u32 per_block = 4 * S;
     u32 blocks = (groups + per_block - 1) / per_block;
-    hipLaunchKernelGGL((k_decode_flat<G>), dim3(blocks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_decode_flat<G, S>), dim3(blocks), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
 
-/* the batch (flat) kernel: lanes_per_stream 1, 2 or 4 */
-extern "C" int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, unsigned groups, void *stream)
+/* the batch (flat) kernel: lanes_per_stream 1, 2 or 4; half != 0: half-filled wavefronts, two per SIMD */
+extern "C" int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, int half, unsigned groups, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     switch (lanes_per_stream) {
-    case 1: return launch_flat_t<1>(*p, groups, st);
-    case 2: return launch_flat_t<2>(*p, groups, st);
-    case 4: return launch_flat_t<4>(*p, groups, st);
+    case 1: return half ? launch_flat_t<1, 32>(*p, groups, st) : launch_flat_t<1, 64>(*p, groups, st);
+    case 2: return launch_flat_t<2, 32>(*p, groups, st);
+    case 4: return launch_flat_t<4, 16>(*p, groups, st);
     }
     return -1;
 }

@@ -25,7 +25,7 @@ extern const unsigned char ys_transforms[2420];
 int ys_upload_constants(const u8 *lut768);
 int ys_upload_check_constants(const u32 *x2n);
 int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned groups, void *stream);
-int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, unsigned groups, void *stream);
+int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, int half, unsigned groups, void *stream);
 int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec, unsigned n, unsigned kind, u64 seed,
                     void *stream);
 int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed, u64 *out, void *stream);
@@ -227,8 +227,10 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     /* 1, 2, 4 lanes: the batch kernel (streams of a wavefront in lock step, flat command loop);
        8, 16, 64 lanes: the cooperative kernel (wide copies, lowest latency per stream) */
     const bool flat = lanes <= 4;
-    unsigned per_block = 256u / (unsigned)lanes;
-    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? 1 : 4);
+    /* one stream per lane, half-filled wavefronts: two wavefronts per SIMD instead of one */
+    const int half = lanes == 1 && env_int("YEAST_HALF", 0);
+    unsigned per_block = 256u / (unsigned)lanes / (half ? 2u : 1u);
+    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half ? 2 : 1) : 4);
     size_t want_blocks = (n + per_block - 1) / per_block;
     size_t max_blocks = (size_t)d.cus * blocks_per_cu;
     unsigned blocks = (unsigned)(want_blocks < max_blocks ? want_blocks : max_blocks);
@@ -261,7 +263,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     p.n = (u32)n;
     p.dict = d.d_dict;
     p.xforms = d.d_xf;
-    int e = flat ? ys_launch_decode_flat(&p, lanes, groups, st) : ys_launch_decode(&p, lanes, cmp, groups, st);
+    int e = flat ? ys_launch_decode_flat(&p, lanes, half, groups, st) : ys_launch_decode(&p, lanes, cmp, groups, st);
     if (e)
         return fail("decode launch", (hipError_t)e);
 

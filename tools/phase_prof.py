@@ -21,5 +21,14 @@ hdr = (ck & 0xfffff).astype(np.float64) * 1024
 loop = ((ck >> 20) & 0xfffff).astype(np.float64) * 1024
 drain = ((ck >> 40) & 0xfffff).astype(np.float64) * 1024
 print("rc ok:", (r["rc"] == 0).all())
+look = (r["used"] & 0xffffffff).astype(np.float64) * 1024
+trips = (r["used"] >> 32).astype(np.float64)
+drains = r["flags"].astype(np.float64)
+print("per stream: trips mean %.0f max %.0f; drains mean %.0f; lookup wait %.0f cycles (%.1f%% of loop), per trip %.0f; drain per drain %.0f cycles; loop per trip %.0f"
+      % (trips.mean(), trips.max(), drains.mean(), look.mean(), 100 * look.mean() / loop.mean(), look.mean() / trips.mean(), drain.mean() / max(drains.mean(), 1), loop.mean() / trips.mean()))
 print("cycles/stream (constant 100 MHz counter?) mean: header %.0f  loop %.0f  of which drain %.0f" % (hdr.mean(), loop.mean(), drain.mean()))
 print("header share %.1f%%, drain share of loop %.1f%%" % (100 * hdr.mean() / (hdr.mean() + loop.mean()), 100 * drain.mean() / loop.mean()))
+g = r["got"]
+print("per stream at drain triggers: need %.0f  queue full %.0f;  uppercase words %.0f; drain load phases %.0f cycles (text streams: need %.0f; markov: need %.0f)"
+      % ((g & 0xfff).mean(), ((g >> 12) & 0xfff).mean(), ((g >> 24) & 0xfff).mean(), (g >> 36).astype(np.float64).mean() * 1024,
+         (g & 0xfff)[order < 192].mean(), (g & 0xfff)[order >= 192].mean()))
