@@ -27,21 +27,37 @@ __constant__ u32 c_x2n[68]; /* x^(2^k) mod P for the CRC-32C combine */
 
 DEV u32 rol32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
 DEV u64 rol64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
-DEV u32 ld32(const u8 *p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
-DEV u64 ld64(const u8 *p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+#define GAS __attribute__((address_space(1)))
+typedef u32 __attribute__((aligned(1))) u32u;
+typedef u64 __attribute__((aligned(1))) u64u;
+DEV u32 ld32(const u8 *p) { return *(const GAS u32u *)p; }
+DEV u64 ld64(const u8 *p) { return *(const GAS u64u *)p; }
+DEV u32 ld8(const u8 *p) { return *(const GAS u8 *)p; }
 DEV u64 xxh64_round(u64 acc, u64 in) { return rol64(acc + in * P64_2, 31) * P64_1; }
 DEV u64 xxh64_merge(u64 h, u64 v) { return (h ^ xxh64_round(0, v)) * P64_1 + P64_4; }
 
-/* lanes 0..3 of the wave each own one accumulator; lane 0 finishes */
-DEV u64 wave_xxh64(const u8 *p, u64 len, u64 seed, u32 lane)
+/* Four lanes per buffer (the hash has four independent accumulators and no more): lane `sub` of
+   the quad owns accumulator sub; every lane of the quad finishes the hash redundantly.  The
+   stripe loop keeps eight loads in flight per lane. */
+DEV u64 quad_xxh64(const u8 *p, u64 len, u64 seed, u32 sub)
 {
     u64 h = 0;
     u64 nstripe = len >> 5;
-    u64 acc = lane == 0 ? seed + P64_1 + P64_2 : lane == 1 ? seed + P64_2 : lane == 2 ? seed : seed - P64_1;
-    if (lane < 4)
-        for (u64 i = 0; i < nstripe; i++)
-            acc = xxh64_round(acc, ld64(p + (i << 5) + (lane << 3)));
-    u64 v1 = __shfl(acc, 0), v2 = __shfl(acc, 1), v3 = __shfl(acc, 2), v4 = __shfl(acc, 3);
+    u64 acc = sub == 0 ? seed + P64_1 + P64_2 : sub == 1 ? seed + P64_2 : sub == 2 ? seed : seed - P64_1;
+    const u8 *q = p + (sub << 3);
+    u64 i = 0;
+    for (; i + 8 <= nstripe; i += 8, q += 256) {
+        u64 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            x[k] = ld64(q + (k << 5));
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            acc = xxh64_round(acc, x[k]);
+    }
+    for (; i < nstripe; i++, q += 32)
+        acc = xxh64_round(acc, ld64(q));
+    u64 v1 = __shfl(acc, 0, 4), v2 = __shfl(acc, 1, 4), v3 = __shfl(acc, 2, 4), v4 = __shfl(acc, 3, 4);
     if (len >= 32) {
         h = rol64(v1, 1) + rol64(v2, 7) + rol64(v3, 12) + rol64(v4, 18);
         h = xxh64_merge(h, v1);
@@ -51,7 +67,8 @@ DEV u64 wave_xxh64(const u8 *p, u64 len, u64 seed, u32 lane)
     } else
         h = seed + P64_5;
     h += len;
-    const u8 *q = p + (nstripe << 5), *end = p + len;
+    const u8 *end = p + len;
+    q = p + (nstripe << 5);
     for (; q + 8 <= end; q += 8)
         h = rol64(h ^ xxh64_round(0, ld64(q)), 27) * P64_1 + P64_4;
     if (q + 4 <= end) {
@@ -59,30 +76,43 @@ DEV u64 wave_xxh64(const u8 *p, u64 len, u64 seed, u32 lane)
         q += 4;
     }
     for (; q < end; q++)
-        h = rol64(h ^ (u64)*q * P64_5, 11) * P64_1;
+        h = rol64(h ^ (u64)ld8(q) * P64_5, 11) * P64_1;
     h ^= h >> 33; h *= P64_2; h ^= h >> 29; h *= P64_3; h ^= h >> 32;
     return h;
 }
 
-DEV u32 wave_xxh32(const u8 *p, u64 len, u32 seed, u32 lane)
+DEV u32 xxh32_round(u32 acc, u32 in) { return rol32(acc + in * P32_2, 13) * P32_1; }
+
+DEV u32 quad_xxh32(const u8 *p, u64 len, u32 seed, u32 sub)
 {
     u32 h;
     u64 nstripe = len >> 4;
-    u32 acc = lane == 0 ? seed + P32_1 + P32_2 : lane == 1 ? seed + P32_2 : lane == 2 ? seed : seed - P32_1;
-    if (lane < 4)
-        for (u64 i = 0; i < nstripe; i++)
-            acc = rol32(acc + ld32(p + (i << 4) + (lane << 2)) * P32_2, 13) * P32_1;
-    u32 v1 = __shfl(acc, 0), v2 = __shfl(acc, 1), v3 = __shfl(acc, 2), v4 = __shfl(acc, 3);
+    u32 acc = sub == 0 ? seed + P32_1 + P32_2 : sub == 1 ? seed + P32_2 : sub == 2 ? seed : seed - P32_1;
+    const u8 *q = p + (sub << 2);
+    u64 i = 0;
+    for (; i + 8 <= nstripe; i += 8, q += 128) {
+        u32 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            x[k] = ld32(q + (k << 4));
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            acc = xxh32_round(acc, x[k]);
+    }
+    for (; i < nstripe; i++, q += 16)
+        acc = xxh32_round(acc, ld32(q));
+    u32 v1 = __shfl(acc, 0, 4), v2 = __shfl(acc, 1, 4), v3 = __shfl(acc, 2, 4), v4 = __shfl(acc, 3, 4);
     if (len >= 16)
         h = rol32(v1, 1) + rol32(v2, 7) + rol32(v3, 12) + rol32(v4, 18);
     else
         h = seed + P32_5;
     h += (u32)len;
-    const u8 *q = p + (nstripe << 4), *end = p + len;
+    const u8 *end = p + len;
+    q = p + (nstripe << 4);
     for (; q + 4 <= end; q += 4)
         h = rol32(h + ld32(q) * P32_3, 17) * P32_4;
     for (; q < end; q++)
-        h = rol32(h + (u32)*q * P32_5, 11) * P32_1;
+        h = rol32(h + ld8(q) * P32_5, 11) * P32_1;
     h ^= h >> 15; h *= P32_2; h ^= h >> 13; h *= P32_3; h ^= h >> 16;
     return h;
 }
@@ -113,18 +143,40 @@ DEV u32 crc_x8n(u64 n)
     return p;
 }
 
-/* each lane takes a contiguous slice, then the slices are combined with the
-   zeros operator (crc32c_zeros_op/crc32c_shift, crc32c.c:82-134) in its
-   polynomial form */
-DEV u32 wave_crc32c(const u32 *tab /*LDS, 256*/, const u8 *p, u64 len, u32 init, u32 lane)
+/* four bytes of the message at once: slicing-by-4 over the tables tab[k][b] = CRC of byte b
+   followed by k zero bytes (tab[0] is the byte table of crc32c.c:25-42) */
+DEV u32 crc_word(const u32 *tab, u32 crc, u32 w)
 {
-    u64 per = (len + 63) >> 6;
+    crc ^= w;
+    return tab[768 + (crc & 255)] ^ tab[512 + ((crc >> 8) & 255)] ^ tab[256 + ((crc >> 16) & 255)] ^ tab[crc >> 24];
+}
+
+/* each lane takes a contiguous slice (a multiple of 16 bytes, read 16 bytes at a time), then the
+   slices are combined with the zeros operator (crc32c_zeros_op/crc32c_shift, crc32c.c:82-134) in
+   its polynomial form */
+DEV u32 wave_crc32c(const u32 *tab /*LDS, 4 x 256*/, const u8 *p, u64 len, u32 init, u32 lane)
+{
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((aligned(1))) u32x4u;
+    u64 per = (((len + 63) >> 6) + 15) & ~15ull;
     u64 a = per * lane, e = a + per;
     if (a > len) a = len;
     if (e > len) e = len;
     u32 crc = lane == 0 ? ~init : 0xffffffffu;
-    for (u64 i = a; i < e; i++)
-        crc = tab[(crc ^ p[i]) & 255] ^ (crc >> 8);
+    u64 i = a;
+    for (; i + 32 <= e; i += 32) {
+        u32x4 x = *(const GAS u32x4u *)(p + i), y = *(const GAS u32x4u *)(p + i + 16);
+        crc = crc_word(tab, crc, x.x);
+        crc = crc_word(tab, crc, x.y);
+        crc = crc_word(tab, crc, x.z);
+        crc = crc_word(tab, crc, x.w);
+        crc = crc_word(tab, crc, y.x);
+        crc = crc_word(tab, crc, y.y);
+        crc = crc_word(tab, crc, y.z);
+        crc = crc_word(tab, crc, y.w);
+    }
+    for (; i < e; i++)
+        crc = tab[(crc ^ ld8(p + i)) & 255] ^ (crc >> 8);
     crc = ~crc;
     /* shift by the bytes that follow this slice and fold */
     u32 part = crc_mul(crc_x8n(len - e), crc);
@@ -134,35 +186,50 @@ DEV u32 wave_crc32c(const u32 *tab /*LDS, 256*/, const u8 *p, u64 len, u32 init,
     return part;
 }
 
+DEV void crc_tables(u32 *tab /*LDS, 4 x 256*/)
+{
+    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
+        u32 c = i;
+        for (int k = 0; k < 8; k++)
+            c = (c & 1) ? (c >> 1) ^ CRC_POLY : c >> 1;
+        tab[i] = c;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
+        u32 c = tab[i];
+        for (int k = 1; k < 4; k++) {
+            c = tab[c & 255] ^ (c >> 8);
+            tab[k * 256 + i] = c;
+        }
+    }
+    __syncthreads();
+}
+
 /* kind: 1 = CRC-32C, 2 = XXH32, 3 = XXH64 (seed / initial value 0 at every
    reference call site: brand.c:245-248, broad.c:278-281) */
 __global__ __launch_bounds__(256) void k_check(const u8 *dst, const u64 *dst_off, ys_record *rec, u32 n,
                                                u32 kind, u64 seed, int only_ok)
 {
-    __shared__ u32 s_tab[256];
-    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
-        u32 c = i;
-        for (int k = 0; k < 8; k++)
-            c = (c & 1) ? (c >> 1) ^ CRC_POLY : c >> 1;
-        s_tab[i] = c;
-    }
-    __syncthreads();
-    u32 lane = threadIdx.x & 63;
-    u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    u32 nwave = (gridDim.x * blockDim.x) >> 6;
-    for (u32 j = wave; j < n; j += nwave) {
+    __shared__ u32 s_tab[1024];
+    crc_tables(s_tab);
+    /* CRC-32C: one wavefront per stream (64 slices); the xxHashes: four lanes per stream */
+    const u32 gsz = kind == 1 ? 64 : 4;
+    u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 sub = tid & (gsz - 1);
+    u32 ngroup = (gridDim.x * blockDim.x) / gsz;
+    for (u32 j = tid / gsz; j < n; j += ngroup) {
         ys_record r = rec[j];
         if (only_ok && r.rc != YS_OK && r.rc != YS_MISMATCH && r.rc != YS_EOF && r.rc != YS_INVALID)
             continue;
         const u8 *p = dst + dst_off[j];
         u64 v;
         if (kind == 1)
-            v = wave_crc32c(s_tab, p, r.got, (u32)seed, lane);
+            v = wave_crc32c(s_tab, p, r.got, (u32)seed, sub);
         else if (kind == 2)
-            v = wave_xxh32(p, r.got, (u32)seed, lane);
+            v = quad_xxh32(p, r.got, (u32)seed, sub);
         else
-            v = wave_xxh64(p, r.got, seed, lane);
-        if (lane == 0)
+            v = quad_xxh64(p, r.got, seed, sub);
+        if (sub == 0)
             rec[j].check = v;
     }
 }
@@ -170,22 +237,16 @@ __global__ __launch_bounds__(256) void k_check(const u8 *dst, const u64 *dst_off
 /* plain buffers: one wave per (ptr,len) pair */
 __global__ __launch_bounds__(64) void k_check_buf(const u8 *p, u64 len, u32 kind, u64 seed, u64 *out)
 {
-    __shared__ u32 s_tab[256];
-    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
-        u32 c = i;
-        for (int k = 0; k < 8; k++)
-            c = (c & 1) ? (c >> 1) ^ CRC_POLY : c >> 1;
-        s_tab[i] = c;
-    }
-    __syncthreads();
+    __shared__ u32 s_tab[1024];
+    crc_tables(s_tab);
     u32 lane = threadIdx.x & 63;
     u64 v;
     if (kind == 1)
         v = wave_crc32c(s_tab, p, len, (u32)seed, lane);
     else if (kind == 2)
-        v = wave_xxh32(p, len, (u32)seed, lane);
+        v = quad_xxh32(p, len, (u32)seed, lane & 3);
     else
-        v = wave_xxh64(p, len, seed, lane);
+        v = quad_xxh64(p, len, seed, lane & 3);
     if (lane == 0)
         *out = v;
 }
@@ -201,8 +262,9 @@ extern "C" int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec
                                u64 seed, void *stream)
 {
     if (n == 0) return 0;
-    u32 waves = n < 256 * 16 ? n : 256 * 16;
-    u32 blocks = (waves + 3) / 4;
+    u64 per_block = kind == 1 ? 4 : 64; /* streams a block of 256 lanes takes at a time */
+    u64 want = (n + per_block - 1) / per_block;
+    u32 blocks = (u32)(want < 256 * 8 ? want : 256 * 8);
     hipLaunchKernelGGL(k_check, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, dst_off, rec, n, kind,
                        seed, 1);
     return (int)hipGetLastError();
