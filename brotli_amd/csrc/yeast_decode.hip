@@ -1189,7 +1189,7 @@ DEV u64 spread8(u32 b)
 template <int G, int S, bool SIMPLE>
 DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
 {
-    enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3, ACT_NONE = 4 };
+    enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3, ACT_NONE = 4, ST_COPY = 5 };
     enum { K_FAR = 0, K_BYTES = 1, K_SLOW = 2, K_DICT = 3 };
     Rd &r = c.r;
     WaveLds<S> *wl = (WaveLds<S> *)c.wl;
@@ -1425,9 +1425,16 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         qn = 0;
         flush(c.outp, false);
     };
+    /* The distance and copy code is the longest part of a trip and only about a third of the
+       streams are at a distance symbol on any one trip, so it runs on odd trips only: a stream
+       that reaches a distance on an even trip sits that trip out, and the code runs half as
+       often with about twice as many streams ready for it. */
+    u32 odd = 1;
     while (st != ST_END) {
-        /* a literal whose context bytes are still queued waits for the next drain */
-        const bool hold = st == ST_LIT && ctx && stale;
+        odd ^= 1;
+        /* sits out: a literal whose context bytes are still queued (it waits for the next
+           drain), a distance or an implicit-distance copy on an even trip */
+        const bool hold = (st == ST_LIT && ctx && stale) || ((st == ST_DIST || st == ST_COPY) && !odd);
         if (!SIMPLE) {
             if (!link && !hold) {
                 if (st == ST_CMD) {
@@ -1448,7 +1455,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
                         }
                         c.L.left--;
                     }
-                } else {
+                } else if (st == ST_DIST) {
                     if (c.D.num > 1) {
                         if (c.D.left == 0)
                             switch_block(c, c.D);
@@ -1493,9 +1500,10 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             pn_valid = 0;
         }
         bool first_half = !link && l > ROOT;
-        first_half = first_half && !hold;
-        link = first_half ? e : 0;
-        l = first_half || hold ? 0 : l;
+        const bool nolook = hold || st == ST_COPY; /* nothing is decoded for this stream on this trip */
+        first_half = first_half && !nolook;
+        link = first_half ? e : hold ? link : 0; /* the second half of a long distance code may have to wait */
+        l = first_half || nolook ? 0 : l;
         u32 act = first_half || hold ? (u32)ACT_NONE : st;
         if (l > r.have) {
             rd_eof(r);
@@ -1547,8 +1555,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             }
             mlen -= insert;
             implicit = sym < 128;
-            st = insert ? (u32)ST_LIT : implicit ? (u32)ST_CMD : (u32)ST_DIST;
-            do_copy = !insert && implicit;
+            st = insert ? (u32)ST_LIT : implicit ? (u32)ST_COPY : (u32)ST_DIST;
         } else if (act == ST_LIT) {
             rb[ring_at<S>(slot, (u32)(u64)c.outp)] = (u8)sym;
             c.outp++;
@@ -1556,10 +1563,13 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             c.p2 = c.p1;
             c.p1 = sym;
             if (--insert == 0) {
-                st = mlen == 0 ? (u32)ST_END : implicit ? (u32)ST_CMD : (u32)ST_DIST; /* :1227 */
-                do_copy = mlen != 0 && implicit;
+                st = mlen == 0 ? (u32)ST_END : implicit ? (u32)ST_COPY : (u32)ST_DIST; /* :1227 */
             }
-        } else if (act == ST_DIST) { /* distance(): yeast.c:761-789 */
+        }
+        if (odd) {
+        if (act == ST_COPY)
+            do_copy = true; /* the distance is the newest one of the ring */
+        else if (act == ST_DIST) { /* distance(): yeast.c:761-789 */
             u32 ds = sym;
             if (ds < 16) {
                 u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
@@ -1662,6 +1672,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
             u32 room = c.wsize - maxd;
             maxd += nout < room ? nout : room;
             st = mlen ? (u32)ST_CMD : (u32)ST_END;
+        }
         }
         st = r.rc ? (u32)ST_END : st;
         /* second pass, the whole wavefront at once: when some queue is full, some ring is nearly
