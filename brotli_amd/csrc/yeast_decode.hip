@@ -706,6 +706,7 @@ struct Ctx {
     void *wl; /* WaveLds<S> of this wavefront (batch kernel only) */
 #ifdef YS_PROFILE
     u64 t_hdr, t_loop, t_drain, t_look, t_dload;
+    u64 t_s0, t_s2, t_s3, t_s4, t_s5, t_mark;
     u32 n_trips, n_drains, n_need, n_qfull, n_rfull, n_ents;
 #endif
 };
@@ -1158,6 +1159,12 @@ DEV void emit_raw(Ctx &c, const u8 *from, u32 n, u32 sub)
 DEV void group_sync_mem() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 /* ------------------------------------------------ batch kernel command loop */
+#ifdef YS_PROFILE
+#define YS_MARK(field) do { u64 now_ = __builtin_readcyclecounter(); c.field += now_ - c.t_mark; c.t_mark = now_; } while (0)
+#else
+#define YS_MARK(field) do { } while (0)
+#endif
+
 
 struct FlatEnv {
     const u32 *itab, *dtab, *lit_tab;
@@ -1430,6 +1437,9 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
        that reaches a distance on an even trip sits that trip out, and the code runs half as
        often with about twice as many streams ready for it. */
     u32 odd = 1;
+#ifdef YS_PROFILE
+    c.t_mark = __builtin_readcyclecounter();
+#endif
     while (st != ST_END) {
         odd ^= 1;
         /* sits out: a literal whose context bytes are still queued (it waits for the next
@@ -1479,13 +1489,11 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         rd_refill(r); /* consumes a word that is in a register already; starts the next prefetch */
         u32 peek = (u32)r.w;
         u32 idx = link ? (link >> 4) + ((peek >> ROOT) & ((1u << ((link & 15) - ROOT)) - 1)) : (peek & 255);
-#ifdef YS_PROFILE
-        u64 tl0 = __builtin_readcyclecounter();
-#endif
+        YS_MARK(t_s0);
         u32 e = gld16((const u16 *)(c.ws + off) + idx);
 #ifdef YS_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(e));
-        c.t_look += __builtin_readcyclecounter() - tl0;
+        YS_MARK(t_look);
         c.n_trips++;
 #endif
         /* what this trip does with the entry; ACT_NONE = first half of a long code, or failed */
@@ -1544,6 +1552,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         r.w >>= n2;
         r.have -= n2;
 
+        YS_MARK(t_s2);
         bool do_copy = false;
         i64 dist = c.r0;
         if (act == ST_CMD) {
@@ -1566,6 +1575,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
                 st = mlen == 0 ? (u32)ST_END : implicit ? (u32)ST_COPY : (u32)ST_DIST; /* :1227 */
             }
         }
+        YS_MARK(t_s3);
         if (odd) {
         if (act == ST_COPY)
             do_copy = true; /* the distance is the newest one of the ring */
@@ -1675,6 +1685,7 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
         }
         }
         st = r.rc ? (u32)ST_END : st;
+        YS_MARK(t_s4);
         /* second pass, the whole wavefront at once: when some queue is full, some ring is nearly
            full, or some stream needs bytes that are still queued */
         bool need = st == ST_LIT && ctx && stale;
@@ -1694,10 +1705,12 @@ DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
 #ifdef YS_PROFILE
             c.t_drain += __builtin_readcyclecounter() - td0;
             c.n_drains++;
+            c.t_mark = __builtin_readcyclecounter();
 #endif
         }
         if (st == ST_LIT && ctx)
             offL = next_lit_table();
+        YS_MARK(t_s5);
     }
     /* metablock end (or failure): drain what is queued -- everything queued was valid -- and
        bring the output region up to date */
@@ -2021,6 +2034,7 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     c.need = 0;
 #ifdef YS_PROFILE
     c.t_hdr = c.t_loop = c.t_drain = c.t_look = c.t_dload = 0;
+    c.t_s0 = c.t_s2 = c.t_s3 = c.t_s4 = c.t_s5 = c.t_mark = 0;
     c.n_trips = c.n_drains = c.n_need = c.n_qfull = c.n_rfull = c.n_ents = 0;
 #endif
     c.dict = p.dict;
@@ -2065,6 +2079,10 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     rec.check = ((c.t_hdr >> 10) & 0xfffff) | (((c.t_loop >> 10) & 0xfffff) << 20) | (((c.t_drain >> 10) & 0xfffff) << 40);
     rec.used = (c.t_look >> 10) | ((u64)c.n_trips << 32);
     rec.flags = c.n_drains;
+    if (sub == 0 && c.cap >= 64) {
+        u64 *prof = (u64 *)c.out; /* the profile build's output bytes are not meant to be looked at */
+        prof[0] = c.t_s0; prof[1] = c.t_look; prof[2] = c.t_s2; prof[3] = c.t_s3; prof[4] = c.t_s4; prof[5] = c.t_s5;
+    }
     rec.got = (u64)(c.n_need & 0xfff) | ((u64)(c.n_qfull & 0xfff) << 12) | ((u64)(c.n_rfull & 0xfff) << 24) | ((c.t_dload >> 10) << 36);
 #endif
     p.rec[job] = rec;

@@ -228,7 +228,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
        8, 16, 64 lanes: the cooperative kernel (wide copies, lowest latency per stream) */
     const bool flat = lanes <= 4;
     /* one stream per lane, half-filled wavefronts: two wavefronts per SIMD instead of one */
-    const int half = lanes == 1 && env_int("YEAST_HALF", 0);
+    const int half = lanes == 1 && env_int("YEAST_HALF", 1);
     unsigned per_block = 256u / (unsigned)lanes / (half ? 2u : 1u);
     unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half ? 2 : 1) : 4);
     size_t want_blocks = (n + per_block - 1) / per_block;

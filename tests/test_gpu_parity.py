@@ -69,9 +69,12 @@ def test_misc_encoder_parameters():
         assert "%08x" % r[4] == m["crc32c"]
 
 
-@pytest.mark.parametrize("lanes", [64, 16, 8, 4, 2, 1])
+@pytest.mark.parametrize("lanes", [64, 16, 8, 4, 2, 1, -1])
 def test_cfg2_batch_every_group_width(lanes, monkeypatch):
     meta, streams = H.packed_streams("cfg2_streams")
+    if lanes < 0:  # one stream per lane in full wavefronts (the default is half-filled ones, two per SIMD)
+        lanes = 1
+        monkeypatch.setenv("YEAST_HALF", "0")
     monkeypatch.setenv("YEAST_LANES", str(lanes))
     many = streams * 9  # 2,304 streams: above the threshold where the batch path picks YEAST_LANES
     res = ba.yeast_batch(many, ba.CHECK_XXH64)

@@ -32,3 +32,14 @@ g = r["got"]
 print("per stream at drain triggers: need %.0f  queue full %.0f;  uppercase words %.0f; drain load phases %.0f cycles (text streams: need %.0f; markov: need %.0f)"
       % ((g & 0xfff).mean(), ((g >> 12) & 0xfff).mean(), ((g >> 24) & 0xfff).mean(), (g >> 36).astype(np.float64).mean() * 1024,
          (g & 0xfff)[order < 192].mean(), (g & 0xfff)[order >= 192].mean()))
+sec = np.zeros((n, 6))
+host = b.dst.cpu().numpy()
+for i in range(0, n, 64):  # lane 0 of every wavefront
+    o = int(b.host_dst_off[i])
+    sec[i] = host[o:o + 48].view(np.uint64)
+m = sec[::64].mean(0)
+names = ["top (refill, address)", "lookup wait", "decode + extra bits", "command / literal", "distance + copy (odd trips)", "bottom (trigger, next literal table)"]
+tr = trips[::64].mean()
+print("main-loop sections, cycles per trip (lane 0 of each wavefront; drain excluded):")
+for k in range(6):
+    print("  %-40s %7.0f" % (names[k], m[k] / tr))
