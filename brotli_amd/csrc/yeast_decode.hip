@@ -25,10 +25,8 @@
  * loop head.  That keeps the hot loops free of per-read exit paths.
  */
 #include <hip/hip_runtime.h>
-#include "yeast_common.h"
+#include "yeast_dev.h"
 
-#define DEV __device__ __forceinline__
-#define NOINL __device__ __noinline__
 #ifndef YS_MIN_WAVES
 #define YS_MIN_WAVES 4
 #endif
@@ -65,550 +63,6 @@ DEV void shared_fill(Shared &sh, const u8 *xforms)
     __syncthreads();
 }
 
-/* every access below is to global memory: say so, or pointers that travelled through an
-   out-of-line call are treated as generic and cost flat_* instructions */
-#define GAS __attribute__((address_space(1)))
-DEV u32 gld8(const void *p) { return *(const GAS u8 *)p; }
-DEV u32 gld16(const void *p) { return *(const GAS u16 *)p; }
-DEV u32 gld32(const void *p) { return *(const GAS u32 *)p; }
-DEV u64 gld64u(const void *p) /* unaligned */
-{
-    typedef u64 __attribute__((aligned(1))) u64u;
-    return *(const GAS u64u *)p;
-}
-DEV u32 gld16u(const void *p) /* unaligned */
-{
-    typedef u16 __attribute__((aligned(1))) u16u;
-    return *(const GAS u16u *)p;
-}
-DEV void gst8(void *p, u32 v) { *(GAS u8 *)p = (u8)v; }
-DEV void gst16(void *p, u32 v) { *(GAS u16 *)p = (u16)v; }
-DEV void gst32(void *p, u32 v) { *(GAS u32 *)p = v; }
-DEV void gst64(void *p, u64 v) { *(GAS u64 *)p = v; }
-DEV void gst64u(void *p, u64 v)
-{
-    typedef u64 __attribute__((aligned(1))) u64u;
-    *(GAS u64u *)p = v;
-}
-
-/* ------------------------------------------------------------- bit reader */
-
-struct Rd {
-    const u32 *p; /* 4-byte aligned base at or before the current seek point */
-    u32 idx;      /* dword index (from p) of the word held in nxt */
-    u32 nxt;      /* prefetched dword */
-    u64 w;        /* window, next bit at bit 0 */
-    u32 have;     /* valid bits in w */
-    u32 rem;      /* valid bits of the stream not yet moved into w */
-    u32 total;    /* 8 * stream length */
-    u32 rc;       /* sticky status */
-    u32 fpos;     /* bits consumed when rc was set */
-    u32 dry;      /* the reader ran out of input: the reference had pulled every byte */
-};
-
-DEV u32 rd_pos(const Rd &r) { return r.rc ? r.fpos : r.total - r.rem - r.have; }
-
-DEV void rd_fail(Rd &r, u32 code)
-{
-    if (!r.rc) {
-        r.fpos = r.total - r.rem - r.have;
-        r.rc = code;
-    }
-    r.have = 0;
-    r.rem = 0;
-}
-
-DEV void rd_seek(Rd &r, const u8 *src, u32 bitpos)
-{
-    const u8 *at = src + (bitpos >> 3);
-    u32 mis = (u32)((uintptr_t)at & 3);
-    r.p = (const u32 *)(at - mis);
-    u32 sh = mis * 8 + (bitpos & 7);
-    u64 lo = gld32(r.p), hi = gld32(r.p + 1);
-    r.w = (lo | (hi << 32)) >> sh;
-    u32 left = r.total - bitpos;
-    r.have = 64 - sh < left ? 64 - sh : left;
-    r.rem = left - r.have;
-    r.nxt = gld32(r.p + 2);
-    r.idx = 2;
-}
-
-DEV void rd_refill(Rd &r)
-{
-    if (r.have <= 32) {
-        r.w |= (u64)r.nxt << r.have;
-        u32 add = r.rem < 32 ? r.rem : 32;
-        r.have += add;
-        r.rem -= add;
-        r.idx += add ? 1 : 0; /* never runs more than two words past the end */
-        r.nxt = gld32(r.p + r.idx);
-    }
-}
-
-DEV void rd_eof(Rd &r)
-{
-    if (!r.rc)
-        r.dry = 1;
-    rd_fail(r, YS_EOF);
-}
-
-/* bits(): yeast.c:163-179.  n <= 25.  On exhaustion the reference has pulled
-   every input byte (yeast.c:169-175): dry is set and reported as *len. */
-DEV u32 take(Rd &r, u32 n)
-{
-    rd_refill(r);
-    if (n > r.have) {
-        rd_eof(r);
-        n = 0;
-    }
-    u32 v = (u32)r.w & ((1u << n) - 1);
-    r.w >>= n;
-    r.have -= n;
-    return v;
-}
-
-/* "s->left && s->bits": the rest of the current byte is not zero.  Bits enter
-   the window in whole bytes, so the bits left in the current byte are have % 8. */
-DEV bool tail_nonzero(const Rd &r)
-{
-    u32 k = r.have & 7;
-    return k && ((u32)r.w & ((1u << k) - 1));
-}
-
-/* drop the rest of the current byte; returns the new bit position */
-DEV u32 rd_align(Rd &r)
-{
-    u32 k = r.have & 7;
-    r.w >>= k;
-    r.have -= k;
-    return r.total - r.rem - r.have;
-}
-
-/* -------------------------------------------------------------- LUT decode
- * Table entry (u16): bits 0..3 = code length, bits 4..15 = symbol.  In the
- * 256-entry root a length above 8 marks a link: (length - 8) index bits,
- * value = offset of the sub-table from the root, in entries.
- */
-#define ROOT 8
-#define YS_TAB_ENTRIES 1104
-
-DEV u32 dec_sym(Rd &r, const u16 *t)
-{
-    rd_refill(r);
-    u32 peek = (u32)r.w;
-    u32 e = gld16(t + (peek & 255));
-    u32 l = e & 15;
-    if (l > ROOT) {
-        e = gld16(t + (e >> 4) + ((peek >> ROOT) & ((1u << (l - ROOT)) - 1)));
-        l = e & 15;
-    }
-    if (l > r.have) {
-        rd_eof(r);
-        l = 0;
-    }
-    r.w >>= l;
-    r.have -= l;
-    return e >> 4;
-}
-
-/* packed 16 x 16-bit counters in four 64-bit registers (no indexed arrays) */
-struct Cnt16 {
-    u64 q0, q1, q2, q3;
-};
-DEV void cnt_clear(Cnt16 &k) { k.q0 = k.q1 = k.q2 = k.q3 = 0; }
-DEV void cnt_add(Cnt16 &k, u32 i, u32 v)
-{
-    u64 inc = (u64)v << ((i & 3) * 16);
-    u32 q = i >> 2;
-    k.q0 += q == 0 ? inc : 0;
-    k.q1 += q == 1 ? inc : 0;
-    k.q2 += q == 2 ? inc : 0;
-    k.q3 += q == 3 ? inc : 0;
-}
-DEV void cnt_dec(Cnt16 &k, u32 i)
-{
-    u64 inc = (u64)1 << ((i & 3) * 16);
-    u32 q = i >> 2;
-    k.q0 -= q == 0 ? inc : 0;
-    k.q1 -= q == 1 ? inc : 0;
-    k.q2 -= q == 2 ? inc : 0;
-    k.q3 -= q == 3 ? inc : 0;
-}
-DEV u32 cnt_get(const Cnt16 &k, u32 i)
-{
-    u32 q = i >> 2;
-    u64 x = q == 0 ? k.q0 : q == 1 ? k.q1 : q == 2 ? k.q2 : k.q3;
-    return (u32)(x >> ((i & 3) * 16)) & 0xffff;
-}
-
-/* Header-phase state handed to and from the out-of-line header routines. */
-struct Hdr {
-    Rd r;
-    u8 *ws;
-    u32 arena_used, arena_size; /* bytes, relative to ws + YS_WS_ARENA */
-    u32 tab;                    /* result: byte offset of the table from ws */
-    u32 sub, glog;              /* lane within the group, log2(lanes per group) */
-};
-
-/* Build the decode table of a complete canonical code (construct():
- * yeast.c:246-278) from count[] and the symbols already in canonical order at
- * ws+YS_WS_SORT.  The sub-table width is the smallest one that the remaining
- * counts can fill. */
-DEV void build_table(Hdr &h, const Cnt16 &count)
-{
-    h.tab = YS_WS_ARENA + h.arena_used;
-    if (h.arena_used + YS_TAB_ENTRIES * 2 > h.arena_size) {
-        rd_fail(h.r, YS_WORKSPACE);
-        h.tab = YS_WS_ARENA;
-        return;
-    }
-    u16 *t = (u16 *)(h.ws + h.tab);
-    const u16 *sorted = (const u16 *)(h.ws + YS_WS_SORT);
-    const u32 sub = h.sub, glog = h.glog;
-
-    if (cnt_get(count, 0)) { /* one symbol, zero bits */
-        u64 e4 = (u64)(gld16(sorted) << 4) * 0x0001000100010001ull;
-        for (u32 i = sub; i < 64; i += 1u << glog)
-            gst64((u64 *)t + i, e4);
-        h.arena_used += 512;
-        return;
-    }
-    Cnt16 left = count; /* codes not yet placed, per length */
-    u32 code = 0;       /* canonical code, MSB first, of the current length */
-    u32 si = 0;
-    u32 total = 256; /* entries used */
-    u32 sub_base = 0, sub_bits = 0, sub_key = 0xffffffffu;
-    for (u32 len = 1; len <= 15; len++) {
-        code <<= 1;
-        u32 n = cnt_get(count, len);
-        for (u32 k = 0; k < n; k++, si++, code++) {
-            u32 s = gld16(sorted + si);
-            u32 rev = __builtin_bitreverse32(code) >> (32 - len); /* stream bit order */
-            u32 e = (s << 4) | len;
-            if (len <= ROOT) {
-                /* the replicas of one code are spread over the lanes of the group */
-                for (u32 i = rev + (sub << len); i < 256; i += 1u << (len + glog))
-                    gst16(t + i, e);
-            } else {
-                u32 key = rev & 255;
-                if (key != sub_key) { /* open the next sub-table */
-                    sub_key = key;
-                    sub_base = total;
-                    u32 l2 = len;
-                    int room = 1 << (l2 - ROOT);
-                    while (l2 < 15) {
-                        room -= (int)cnt_get(left, l2);
-                        if (room <= 0)
-                            break;
-                        l2++;
-                        room <<= 1;
-                    }
-                    sub_bits = l2 - ROOT;
-                    total += 1u << sub_bits;
-                    if (total > YS_TAB_ENTRIES) { /* cannot happen for a complete code */
-                        rd_fail(h.r, YS_WORKSPACE);
-                        return;
-                    }
-                    gst16(t + key, (sub_base << 4) | (ROOT + sub_bits));
-                }
-                u32 sl = len - ROOT;
-                for (u32 i = (rev >> ROOT) + (sub << sl); i < (1u << sub_bits); i += 1u << (sl + glog))
-                    gst16(t + sub_base + i, e);
-            }
-            cnt_dec(left, len);
-        }
-    }
-    h.arena_used += (total * 2 + 15) & ~15u;
-}
-
-/* read_code(): prefix() yeast.c:361-542.  num = alphabet size.  Leaves the
-   table offset in h.tab (always a readable table, even after a failure). */
-NOINL Hdr read_code(Hdr h, u32 num)
-{
-    Rd &r = h.r;
-    u16 *sorted = (u16 *)(h.ws + YS_WS_SORT);
-    h.tab = YS_WS_ARENA;
-    u32 hskip = take(r, 2);
-    Cnt16 count;
-    cnt_clear(count);
-
-    if (hskip == 1) { /* simple code, yeast.c:372-403 and simple() :307-348 */
-        u32 abits = 32 - __builtin_clz(num - 1);
-        u32 nsym = take(r, 2) + 1;
-        u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        for (u32 k = 0; k < nsym; k++) {
-            u32 v = take(r, abits);
-            if (v >= num) {
-                rd_fail(r, YS_INVALID); /* :393 */
-                return h;
-            }
-            if (k == 0) s0 = v;
-            else if (k == 1) s1 = v;
-            else if (k == 2) s2 = v;
-            else s3 = v;
-        }
-        u32 shape = nsym;
-        if (nsym == 4)
-            shape += take(r, 1);
-        if (r.rc)
-            return h;
-#define ORD(a, b) do { if (a > b) { u32 t_ = a; a = b; b = t_; } } while (0)
-        switch (shape) {
-        case 1: cnt_add(count, 0, 1); break;
-        case 2: cnt_add(count, 1, 2); ORD(s0, s1); break;
-        case 3: cnt_add(count, 1, 1); cnt_add(count, 2, 2); ORD(s1, s2); break;
-        case 4:
-            cnt_add(count, 2, 4);
-            ORD(s0, s1); ORD(s2, s3); ORD(s0, s2); ORD(s1, s3); ORD(s1, s2);
-            break;
-        default:
-            cnt_add(count, 1, 1); cnt_add(count, 2, 1); cnt_add(count, 3, 2);
-            ORD(s2, s3);
-        }
-#undef ORD
-        gst16(sorted, s0); gst16(sorted + 1, s1); gst16(sorted + 2, s2); gst16(sorted + 3, s3);
-        build_table(h, count);
-        return h;
-    }
-
-    /* ---- complex code: first the code length code, yeast.c:429-461 ---- */
-    /* fixed code for the code length code lengths (yeast.c:422), indexed by 4 stream bits */
-    const u64 FIX_SYM = 0x5340234013402340ull; /* entry i at bits 4i: symbol */
-    const u64 FIX_LEN = 0x4222322242223222ull; /* entry i at bits 4i: length */
-    u64 clen = 0; /* 18 x 3-bit code length code lengths */
-    int space = 32;
-    u32 nonzero = 0, lastsym = 0;
-    u32 nsym = hskip;
-    /* order[] of yeast.c:415-417 packed 5 bits each */
-    const u64 ORD_LO = (1ull) | (2ull << 5) | (3ull << 10) | (4ull << 15) | (0ull << 20) | (5ull << 25) |
-                       (17ull << 30) | (6ull << 35) | (16ull << 40) | (7ull << 45) | (8ull << 50) | (9ull << 55);
-    const u64 ORD_HI = (10ull) | (11ull << 5) | (12ull << 10) | (13ull << 15) | (14ull << 20) | (15ull << 25);
-    while (nsym < 18) {
-        rd_refill(r);
-        u32 pk = (u32)r.w & 15;
-        u32 l = (u32)(FIX_LEN >> (pk * 4)) & 15;
-        u32 s = (u32)(FIX_SYM >> (pk * 4)) & 15;
-        if (l > r.have) {
-            rd_eof(r);
-            return h;
-        }
-        r.w >>= l; r.have -= l;
-        u32 k = nsym < 12 ? (u32)(ORD_LO >> (nsym * 5)) & 31 : (u32)(ORD_HI >> ((nsym - 12) * 5)) & 31;
-        nsym++;
-        clen |= (u64)s << (k * 3);
-        if (s) {
-            nonzero++;
-            lastsym = k;
-            space -= 32 >> s;
-            if (space <= 0)
-                break;
-        }
-    }
-    if (space < 0 || (space && nonzero != 1)) {
-        rd_fail(r, YS_INVALID); /* over-subscribed :451 / incomplete :453 code length code */
-        return h;
-    }
-
-    /* decode table of the code length code: 32 entries x 8 bits (sym<<3 | len) in registers */
-    u64 q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    if (space) { /* single symbol, zero bits :456-459 */
-        u64 e = (u64)(lastsym << 3) * 0x0101010101010101ull;
-        q0 = q1 = q2 = q3 = e;
-    } else {
-        u32 code = 0;
-        for (u32 len = 1; len <= 5; len++) {
-            code <<= 1;
-            for (u32 s = 0; s < 18; s++) {
-                if (((u32)(clen >> (s * 3)) & 7) != len)
-                    continue;
-                u32 rev = __builtin_bitreverse32(code) >> (32 - len);
-                u64 e = (u64)((s << 3) | len);
-                for (u32 i = rev; i < 32; i += 1u << len) {
-                    u64 m = e << ((i & 7) * 8);
-                    u32 q = i >> 3;
-                    q0 |= q == 0 ? m : 0;
-                    q1 |= q == 1 ? m : 0;
-                    q2 |= q == 2 ? m : 0;
-                    q3 |= q == 3 ? m : 0;
-                }
-                code++;
-            }
-        }
-    }
-
-    /* ---- the code lengths themselves, yeast.c:464-518 ---- */
-    if (h.arena_used + 704 * 2 + 16 + YS_TAB_ENTRIES * 2 > h.arena_size) {
-        rd_fail(r, YS_WORKSPACE);
-        return h;
-    }
-    /* coded symbols as (length << 12 | symbol), in symbol order; scratch above the table's place */
-    u16 *nz = (u16 *)(h.ws + YS_WS_ARENA + h.arena_used + YS_TAB_ENTRIES * 2);
-    u32 nnz = 0;
-    int left = 1 << 15;
-    u32 prev = 8, rep = 0, zeros = 0, n;
-    nsym = 0;
-    do {
-        rd_refill(r);
-        u32 pk = (u32)r.w & 31;
-        u32 q = pk >> 3;
-        u64 x = q == 0 ? q0 : q == 1 ? q1 : q == 2 ? q2 : q3;
-        u32 e = (u32)(x >> ((pk & 7) * 8)) & 255;
-        u32 l = e & 7;
-        if (l > r.have) {
-            rd_eof(r);
-            return h;
-        }
-        r.w >>= l; r.have -= l;
-        u32 len = e >> 3;
-        if (len < 16) {
-            if (len) {
-                gst16(nz + nnz++, (len << 12) | nsym);
-                left -= (1 << 15) >> len;
-                prev = len;
-                cnt_add(count, len, 1);
-            }
-            nsym++;
-            rep = 0;
-            zeros = 0;
-        } else if (len == 16) {
-            n = rep;
-            rep = (rep ? (rep - 2) << 2 : 0) + 3 + take(r, 2);
-            n = rep - n;
-            if (r.rc)
-                return h;
-            if (nsym + n > num) {
-                rd_fail(r, YS_INVALID); /* too many repeats :491 */
-                return h;
-            }
-            left -= (int)n * ((1 << 15) >> prev);
-            if (left < 0)
-                break;
-            cnt_add(count, prev, n);
-            for (u32 k = 0; k < n; k++)
-                gst16(nz + nnz++, (prev << 12) | nsym++);
-            zeros = 0;
-        } else {
-            n = zeros;
-            zeros = (zeros ? (zeros - 2) << 3 : 0) + 3 + take(r, 3);
-            n = zeros - n;
-            if (r.rc)
-                return h;
-            if (nsym + n > num) {
-                rd_fail(r, YS_INVALID); /* too many repeats :508 */
-                return h;
-            }
-            nsym += n;
-            rep = 0;
-        }
-    } while (left > 0 && nsym < num);
-    if (left != 0) {
-        rd_fail(r, YS_INVALID); /* incomplete :516 / over-subscribed :518 code */
-        return h;
-    }
-
-    /* counting sort into canonical order (construct() yeast.c:266-277) */
-    Cnt16 offs;
-    cnt_clear(offs);
-    {
-        u32 acc = 0;
-        for (u32 l = 1; l <= 15; l++) {
-            cnt_add(offs, l, acc);
-            acc += cnt_get(count, l);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (u32 i = 0; i < nnz; i++) {
-        u32 e = gld16(nz + i);
-        u32 l = e >> 12;
-        gst16(sorted + cnt_get(offs, l), e & 0xfff);
-        cnt_add(offs, l, 1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    build_table(h, count);
-    return h;
-}
-
-/* block_types(): yeast.c:576-584 */
-DEV u32 read_count256(Rd &r)
-{
-    if (!take(r, 1))
-        return 1;
-    u32 k = take(r, 3);
-    return 1 + (1u << k) + take(r, k);
-}
-
-/* block_length(): yeast.c:550-567; base[]/extra[] from their closed form */
-DEV u32 read_block_count(Rd &r, const u16 *t)
-{
-    u32 s = dec_sym(r, t);
-    u32 base, extra;
-    if (s < 4) { base = 1 + 4 * s; extra = 2; }
-    else if (s < 8) { base = 17 + 8 * (s - 4); extra = 3; }
-    else if (s < 12) { base = 49 + 16 * (s - 8); extra = 4; }
-    else if (s < 16) { base = 113 + 32 * (s - 12); extra = 5; }
-    else if (s < 18) { base = 241 + 64 * (s - 16); extra = 6; }
-    else if (s >= 25) { base = 16625; extra = 24; }
-    else { extra = s - 11; base = 369 + ((1u << (s - 11)) - 128); }
-    return base + take(r, extra);
-}
-
-/* context_map(): yeast.c:589-647.  map has room for len bytes. */
-NOINL Hdr read_context_map(Hdr h, u8 *map, u32 len, u32 trees)
-{
-    Rd &r = h.r;
-    u32 rlemax = 0;
-    if (take(r, 1))
-        rlemax = 1 + take(r, 4);
-    u32 save = h.arena_used;
-    h = read_code(h, rlemax + trees);
-    const u16 *t = (const u16 *)(h.ws + h.tab);
-    h.arena_used = save; /* the map's own code is dead once the map is read */
-    if (r.rc)
-        return h;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    u32 n = 0;
-    do {
-        u32 s = dec_sym(r, t);
-        if (r.rc)
-            return h;
-        if (s == 0)
-            gst8(map + n++, 0);
-        else if (s <= rlemax) {
-            u32 z = (1u << s) + take(r, s);
-            if (r.rc)
-                return h;
-            if (n + z > len) {
-                rd_fail(r, YS_INVALID); /* run length too long :616 */
-                return h;
-            }
-            for (u32 k = 0; k < z; k++)
-                gst8(map + n++, 0);
-        } else
-            gst8(map + n++, s - rlemax);
-    } while (n < len);
-    if (take(r, 1)) { /* inverse move-to-front :629-646 */
-        u8 *tab = h.ws + YS_WS_MTF;
-        for (u32 k = 0; k < trees; k++)
-            gst8(tab + k, k);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (n = 0; n < len; n++) {
-            u32 s = gld8(map + n);
-            if (s >= trees)
-                s = 0; /* unreachable for a valid map; keeps the list index in range */
-            if (s) {
-                u32 front = gld8(tab + s);
-                for (u32 k = s; k; k--)
-                    gst8(tab + k, gld8(tab + k - 1));
-                gst8(tab, front);
-                gst8(map + n, front);
-            } else
-                gst8(map + n, gld8(tab));
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    return h;
-}
-
 /* ------------------------------------------------------------------ state */
 
 /* per-wavefront LDS of the batch kernel: the copy queues, the literal table map and the output
@@ -629,7 +83,6 @@ struct WaveLds {
     u16 lt[64 * S]; /* [context][stream]: byte offset of the literal table >> 4 */
     u64 ring[RU * S]; /* [unit][stream] */
 };
-#define LAS __attribute__((address_space(3)))
 
 /* byte offset of output address a (low bits) in the ring array of a wavefront with S streams */
 template <int S>
@@ -1806,6 +1259,8 @@ DEV u32 metablock(Ctx &c, u32 sub)
     h.tab = YS_WS_ARENA;
     h.sub = sub;
     h.glog = 31 - __builtin_clz((u32)G);
+    h.lds = nullptr; /* tables in the global arena */
+    h.lds_used = h.lds_size = h.rootcaps = 0;
     read_block_header(h, c.L);
     read_block_header(h, c.I);
     read_block_header(h, c.D);

@@ -26,6 +26,9 @@ int ys_upload_constants(const u8 *lut768);
 int ys_upload_check_constants(const u32 *x2n);
 int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned groups, void *stream);
 int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, int half, unsigned groups, void *stream);
+int ysw_upload_constants(const u8 *lut768);
+unsigned ysw_shared_bytes(void);
+int ysw_launch(const ys_params *p, unsigned slot_entries, unsigned rootcaps, unsigned blocks, void *stream);
 int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec, unsigned n, unsigned kind, u64 seed,
                     void *stream);
 int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed, u64 *out, void *stream);
@@ -157,6 +160,8 @@ static int device_get(Device **out)
             x2n[k] = crc_mul(x2n[k - 1], x2n[k - 1]);
         int e = ys_upload_constants(g_luts);
         if (!e)
+            e = ysw_upload_constants(g_luts);
+        if (!e)
             e = ys_upload_check_constants(x2n);
         if (e)
             return fail("upload constants (is a gfx950 code object present?)", (hipError_t)e);
@@ -198,6 +203,8 @@ extern "C" const unsigned char *yeast_debug_table(int which, size_t *size)
 
 /* ---- launch ------------------------------------------------------------------ */
 
+#define YS_LANES_WAVE 65 /* lanes_per_stream value of the wavefront-per-stream batch kernel (LDS tables) */
+
 static int env_int(const char *name, int dflt)
 {
     const char *s = getenv(name);
@@ -216,14 +223,62 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         snprintf(t_err, sizeof(t_err), "libyeast_mi355x: batch too large");
         return -1;
     }
-    if (lanes == 0)
-        lanes = env_int("YEAST_LANES", 1);
+    if (lanes == 0) /* large batches: one stream per lane; small ones: one stream per wavefront, tables in LDS */
+        lanes = env_int("YEAST_LANES", n >= 16384 ? 1 : YS_LANES_WAVE);
     if (cmp)
         lanes = 64;
-    if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 64) {
-        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: lanes_per_stream must be 1, 2, 4, 8, 16 or 64");
+    if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 64 && lanes != YS_LANES_WAVE) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: lanes_per_stream must be 1, 2, 4, 8, 16, 64 or 65");
         return -1;
     }
+    /* counters: [0] main queue head, [1] retry queue head, [2] retry count; then the retry list */
+    if (grow(d.ctr, 16 + n * sizeof(u32)))
+        return -1;
+    HIPCK(hipMemsetAsync(d.ctr.p, 0, 16, st));
+    ys_params p;
+    memset(&p, 0, sizeof(p));
+    p.src = src;
+    p.src_off = soff;
+    p.dst = dst;
+    p.dst_off = doff;
+    p.rec = rec;
+    p.counter = (u32 *)d.ctr.p;
+    p.retry_count = (u32 *)d.ctr.p + 2;
+    p.retry_list = (u32 *)d.ctr.p + 4;
+    p.retry = 0;
+    p.n = (u32)n;
+    p.dict = d.d_dict;
+    p.xforms = d.d_xf;
+    int e;
+    if (lanes == YS_LANES_WAVE) {
+        /* one wavefront per stream, tables in LDS: blocks of four wavefronts; the LDS of a CU is
+           split between the resident blocks, so the slot size sets how many streams a CU holds */
+        unsigned waves_per_cu = (unsigned)env_int("YEAST_WAVES_PER_CU", 16);
+        if (waves_per_cu < 4)
+            waves_per_cu = 4;
+        if (waves_per_cu > 32)
+            waves_per_cu = 32;
+        waves_per_cu &= ~3u;
+        unsigned blocks_per_cu = waves_per_cu / 4;
+        unsigned lds_per_block = (160u * 1024u) / blocks_per_cu;
+        if (lds_per_block > 64u * 1024u)
+            lds_per_block = 64u * 1024u;
+        unsigned slot_entries = ((lds_per_block - ysw_shared_bytes() - 64) / 4 / 2) & ~7u;
+        slot_entries = (unsigned)env_int("YEAST_SLOT_ENTRIES", (int)slot_entries);
+        /* root table widths: literal | insert-and-copy << 8 | others << 16 */
+        unsigned rootcaps = (unsigned)env_int("YEAST_ROOT_LIT", 7) | ((unsigned)env_int("YEAST_ROOT_IAC", 8) << 8) |
+                            ((unsigned)env_int("YEAST_ROOT_OTHER", 8) << 16);
+        size_t want = (n + 3) / 4, maxb = (size_t)d.cus * blocks_per_cu;
+        unsigned blocks = (unsigned)(want < maxb ? want : maxb);
+        u64 stride = 32768; /* header scratch per wavefront: yeast_wave.hip w_metablock() */
+        if (grow(d.ws, (size_t)blocks * 4 * stride))
+            return -1;
+        p.ws = (u8 *)d.ws.p;
+        p.ws_stride = stride;
+        e = ysw_launch(&p, slot_entries, rootcaps, blocks, st);
+        if (e)
+            return fail("decode launch", (hipError_t)e);
+    } else {
     /* 1, 2, 4 lanes: the batch kernel (streams of a wavefront in lock step, flat command loop);
        8, 16, 64 lanes: the cooperative kernel (wide copies, lowest latency per stream) */
     const bool flat = lanes <= 4;
@@ -242,30 +297,12 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         stride = 1u << 20; /* the batch kernel keeps table offsets >> 4 in 16 bits */
     if (grow(d.ws, (size_t)groups * stride))
         return -1;
-    /* counters: [0] main queue head, [1] retry queue head, [2] retry count; then the retry list */
-    if (grow(d.ctr, 16 + n * sizeof(u32)))
-        return -1;
-    HIPCK(hipMemsetAsync(d.ctr.p, 0, 16, st));
-
-    ys_params p;
-    memset(&p, 0, sizeof(p));
-    p.src = src;
-    p.src_off = soff;
-    p.dst = dst;
-    p.dst_off = doff;
-    p.rec = rec;
     p.ws = (u8 *)d.ws.p;
     p.ws_stride = stride;
-    p.counter = (u32 *)d.ctr.p;
-    p.retry_count = (u32 *)d.ctr.p + 2;
-    p.retry_list = (u32 *)d.ctr.p + 4;
-    p.retry = 0;
-    p.n = (u32)n;
-    p.dict = d.d_dict;
-    p.xforms = d.d_xf;
-    int e = flat ? ys_launch_decode_flat(&p, lanes, half, groups, st) : ys_launch_decode(&p, lanes, cmp, groups, st);
+    e = flat ? ys_launch_decode_flat(&p, lanes, half, groups, st) : ys_launch_decode(&p, lanes, cmp, groups, st);
     if (e)
         return fail("decode launch", (hipError_t)e);
+    }
 
     /* retry pass: whole wavefronts, worst-case arena; exits at once when the list is empty */
     const unsigned big_groups = 64;
@@ -398,7 +435,7 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
         if (out)
             out[i] = nullptr;
     }
-    int lanes = n >= 2048 ? 0 : 64;
+    int lanes = env_int("YEAST_FORCE_LANES", n >= 2048 ? 0 : 64); /* the override is for the tests */
 
     while (!todo.empty()) {
         size_t m = todo.size();

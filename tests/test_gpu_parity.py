@@ -58,8 +58,24 @@ def test_testdata_corpus_compare_mode():
     assert gpu_yeast(bytes.fromhex("06"), b"") == H.oracle_yeast(bytes.fromhex("06"), b"")
 
 
-def test_misc_encoder_parameters():
+KERNELS = [64, 65, 1]  # cooperative, wavefront per stream (LDS tables), one stream per lane
+
+
+@pytest.mark.parametrize("lanes", KERNELS)
+def test_crafted_streams_through_every_kernel(lanes, monkeypatch):
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    cr = H.load_json("crafted.json")
+    names = sorted(cr)
+    res = ba.yeast_batch([bytes.fromhex(cr[k]["hex"]) for k in names])
+    for k, r in zip(names, res):
+        v = cr[k]
+        assert (r[0], r[2], r[3], r[1].hex()) == (v["rc"], v["got"], v["used"], v["out"]), k
+
+
+@pytest.mark.parametrize("lanes", KERNELS)
+def test_misc_encoder_parameters(lanes, monkeypatch):
     # window bits 10..24, qualities 0..10, NPOSTFIX/NDIRECT != 0 (unpinned by testdata/)
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
     meta, streams = H.packed_streams("misc_streams")
     res = ba.yeast_batch(streams, ba.CHECK_CRC32C)
     for m, s, r in zip(meta["streams"], streams, res):
@@ -69,7 +85,7 @@ def test_misc_encoder_parameters():
         assert "%08x" % r[4] == m["crc32c"]
 
 
-@pytest.mark.parametrize("lanes", [64, 16, 8, 4, 2, 1, -1])
+@pytest.mark.parametrize("lanes", [65, 64, 16, 8, 4, 2, 1, -1])
 def test_cfg2_batch_every_group_width(lanes, monkeypatch):
     meta, streams = H.packed_streams("cfg2_streams")
     if lanes < 0:  # one stream per lane in full wavefronts (the default is half-filled ones, two per SIMD)
@@ -102,9 +118,11 @@ def test_check_values_known_answers():
     assert ba.xxh32(alice[:777], 12345) == o.oracle_xxh32(alice[:777], 777, 12345)
 
 
-def test_fuzzed_streams_same_error_class_and_progress():
+@pytest.mark.parametrize("lanes", KERNELS)
+def test_fuzzed_streams_same_error_class_and_progress(lanes, monkeypatch):
     # truncations and bit flips of real streams: rc, got, used and the partial output must agree
-    rnd = random.Random(11)
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    rnd = random.Random(11 + lanes)
     meta, streams = H.packed_streams("cfg2_streams")
     _, misc = H.packed_streams("misc_streams")
     cases = []
