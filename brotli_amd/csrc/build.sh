@@ -13,6 +13,8 @@ $HIPCC $FLAGS -c yeast_check.hip -o yeast_check.o &
 P2=$!
 $HIPCC $FLAGS -c yeast_wave.hip -o yeast_wave.o ${YEAST_EXTRA_FLAGS} &
 P4=$!
+$HIPCC $FLAGS -c yeast_lane.hip -o yeast_lane.o ${YEAST_EXTRA_FLAGS} &
+P5=$!
 $HIPCC $FLAGS -c yeast_host.cpp -o yeast_host.o &
 P3=$!
 gcc -O2 -fPIC -DYS_DATA_DIR="\"$DATA\"" -c yeast_data.c -o yeast_data.o
@@ -20,5 +22,6 @@ wait $P1
 wait $P2
 wait $P3
 wait $P4
-$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT/libyeast_mi355x.so" yeast_decode.o yeast_wave.o yeast_check.o yeast_host.o yeast_data.o
+wait $P5
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT/libyeast_mi355x.so" yeast_decode.o yeast_wave.o yeast_lane.o yeast_check.o yeast_host.o yeast_data.o
 echo "built $OUT/libyeast_mi355x.so"

@@ -52,6 +52,10 @@ typedef struct {
     u32 n;
     const u8 *dict;      /* 122,784-byte static dictionary */
     const u8 *xforms;    /* 121 x 20-byte transform records */
+    const u8 *xdict;     /* every transform of every dictionary word (built on the device at start-up) */
+    const u32 *xdict_base; /* [121][21]: byte offset in xdict of (transform, word length 4..24), entries back to back */
+    u32 rootcaps;        /* root table widths: other | literal << 8 | insert-and-copy << 16 | distance << 24;
+                            0 = 8 bits everywhere (the only setting of the kernels other than the lean one) */
 } ys_params;
 
 #define YS_SRC_PAD 32

@@ -200,7 +200,9 @@ struct Hdr {
        wavefront's LDS slot.  Units are u16 entries from the slot base. */
     LAS u16 *lds;
     u32 lds_used, lds_size;
-    u32 rootcaps; /* widest root table: literal codes | insert-and-copy codes << 8 | all others << 16 */
+    u32 rootcaps; /* root table width by kind: other | literal << 8 | insert-and-copy << 16 | distance << 24
+                     (global tables: exactly that wide; LDS mode: at most that wide) */
+    u32 kind;     /* YS_KIND_* of the code read next */
 };
 
 /* A wavefront that decodes ONE stream holds the same value of all of this in every lane, but a
@@ -233,80 +235,111 @@ DEV void hdr_uniform(Hdr &h)
     h.lds_used = uni(h.lds_used);
     h.lds_size = uni(h.lds_size);
     h.rootcaps = uni(h.rootcaps);
+    h.kind = uni(h.kind);
 }
 
 
 /* Build the decode table of a complete canonical code (construct():
- * yeast.c:246-278) from count[] and the symbols already in canonical order at
- * ws+YS_WS_SORT.  The sub-table width is the smallest one that the remaining
- * counts can fill. */
-DEV void build_table(Hdr &h, const Cnt16 &count)
+ * yeast.c:246-278) in the global arena from count[] and the symbols already in
+ * canonical order at ws+YS_WS_SORT.  The root table is exactly `root` bits wide
+ * (the decode loops know the width from what they are decoding, not from the
+ * table).  Layout of the sub-tables: see "LDS mode" below -- the prefixes that
+ * need a sub-table are the highest ones, grouped by the depth they need. */
+DEV void cnt_set(Cnt16 &k, u32 i, u32 v)
+{
+    u64 m = (u64)0xffff << ((i & 3) * 16), x = (u64)v << ((i & 3) * 16);
+    u32 q = i >> 2;
+    k.q0 = q == 0 ? (k.q0 & ~m) | x : k.q0;
+    k.q1 = q == 1 ? (k.q1 & ~m) | x : k.q1;
+    k.q2 = q == 2 ? (k.q2 & ~m) | x : k.q2;
+    k.q3 = q == 3 ? (k.q3 & ~m) | x : k.q3;
+}
+
+DEV void build_table(Hdr &h, const Cnt16 &count, u32 root)
 {
     h.tab = YS_WS_ARENA + h.arena_used;
-    if (h.arena_used + YS_TAB_ENTRIES * 2 > h.arena_size) {
-        rd_fail(h.r, YS_WORKSPACE);
-        h.tab = YS_WS_ARENA;
-        return;
-    }
     u16 *t = (u16 *)(h.ws + h.tab);
     const u16 *sorted = (const u16 *)(h.ws + YS_WS_SORT);
     const u32 sub = h.sub, glog = h.glog;
+    const u32 nroot = 1u << root;
 
     if (cnt_get(count, 0)) { /* one symbol, zero bits */
-        u64 e4 = (u64)(gld16(sorted) << 4) * 0x0001000100010001ull;
-        for (u32 i = sub; i < 64; i += 1u << glog)
-            gst64((u64 *)t + i, e4);
-        h.arena_used += 512;
+        if (h.arena_used + nroot * 2 + 16 > h.arena_size) {
+            rd_fail(h.r, YS_WORKSPACE);
+            h.tab = YS_WS_ARENA;
+            return;
+        }
+        u32 e = gld16(sorted) << 4;
+        for (u32 i = sub; i < nroot; i += 1u << glog)
+            gst16(t + i, e);
+        h.arena_used += (nroot * 2 + 15) & ~15u;
         return;
     }
-    Cnt16 left = count; /* codes not yet placed, per length */
-    u32 code = 0;       /* canonical code, MSB first, of the current length */
+    u32 maxlen = 1;
+    Cnt16 first; /* canonical first code of each length */
+    cnt_clear(first);
+    {
+        u32 code = 0;
+        for (u32 l = 1; l <= 15; l++) {
+            code <<= 1;
+            cnt_set(first, l, code);
+            u32 n = cnt_get(count, l);
+            code += n;
+            maxlen = n ? l : maxlen;
+        }
+    }
+    /* sub-table groups by depth L: sbase = first entry, plow = first prefix */
+    Cnt16 sbase, plow;
+    cnt_clear(sbase);
+    cnt_clear(plow);
+    u32 total = nroot;
+    {
+        u32 pprev = cnt_get(first, root) + cnt_get(count, root); /* prefixes below hold codes up to root bits */
+        for (u32 L = root + 1; L <= maxlen; L++) {
+            u32 pl = (cnt_get(first, L) + cnt_get(count, L)) >> (L - root);
+            cnt_set(plow, L, pprev);
+            cnt_set(sbase, L, total);
+            total += (pl - pprev) << (L - root);
+            pprev = pl;
+        }
+    }
+    if (total > 4096 || h.arena_used + total * 2 + 16 > h.arena_size) {
+        rd_fail(h.r, YS_WORKSPACE); /* redone with 8-bit roots and the worst-case arena */
+        h.tab = YS_WS_ARENA;
+        return;
+    }
     u32 si = 0;
-    u32 total = 256; /* entries used */
-    u32 sub_base = 0, sub_bits = 0, sub_key = 0xffffffffu;
-    for (u32 len = 1; len <= 15; len++) {
-        code <<= 1;
-        u32 n = cnt_get(count, len);
+    u32 grp = root + 1; /* depth group of the current prefix (prefixes only grow) */
+    u32 cur_c = 0xffffffffu, cur_sb = 0;
+    for (u32 len = 1; len <= maxlen; len++) {
+        u32 n = cnt_get(count, len), code = cnt_get(first, len);
         for (u32 k = 0; k < n; k++, si++, code++) {
             u32 s = gld16(sorted + si);
-            u32 rev = __builtin_bitreverse32(code) >> (32 - len); /* stream bit order */
             u32 e = (s << 4) | len;
-            if (len <= ROOT) {
+            if (len <= root) {
                 /* the replicas of one code are spread over the lanes of the group */
-                for (u32 i = rev + (sub << len); i < 256; i += 1u << (len + glog))
+                u32 rev = __builtin_bitreverse32(code) >> (32 - len);
+                for (u32 i = rev + (sub << len); i < nroot; i += 1u << (len + glog))
                     gst16(t + i, e);
             } else {
-                u32 key = rev & 255;
-                if (key != sub_key) { /* open the next sub-table */
-                    sub_key = key;
-                    sub_base = total;
-                    u32 l2 = len;
-                    int room = 1 << (l2 - ROOT);
-                    while (l2 < 15) {
-                        room -= (int)cnt_get(left, l2);
-                        if (room <= 0)
-                            break;
-                        l2++;
-                        room <<= 1;
-                    }
-                    sub_bits = l2 - ROOT;
-                    total += 1u << sub_bits;
-                    if (total > YS_TAB_ENTRIES) { /* cannot happen for a complete code */
-                        rd_fail(h.r, YS_WORKSPACE);
-                        return;
-                    }
-                    gst16(t + key, (sub_base << 4) | (ROOT + sub_bits));
+                u32 sl = len - root;
+                u32 c = code >> sl;
+                if (c != cur_c) { /* first code under this prefix: place its sub-table, write the link */
+                    cur_c = c;
+                    while (grp < maxlen && c >= ((cnt_get(first, grp) + cnt_get(count, grp)) >> (grp - root)))
+                        grp++;
+                    cur_sb = cnt_get(sbase, grp) + ((c - cnt_get(plow, grp)) << (grp - root));
+                    if (sub == 0)
+                        gst16(t + (__builtin_bitreverse32(c) >> (32 - root)), (cur_sb << 4) | grp);
                 }
-                u32 sl = len - ROOT;
-                for (u32 i = (rev >> ROOT) + (sub << sl); i < (1u << sub_bits); i += 1u << (sl + glog))
-                    gst16(t + sub_base + i, e);
+                u32 rev = __builtin_bitreverse32(code & ((1u << sl) - 1)) >> (32 - sl);
+                for (u32 i = rev + (sub << sl); i < (1u << (grp - root)); i += 1u << (sl + glog))
+                    gst16(t + cur_sb + i, e);
             }
-            cnt_dec(left, len);
         }
     }
     h.arena_used += (total * 2 + 15) & ~15u;
 }
-
 
 /* ---- LDS mode ---------------------------------------------------------------------------------
  * Table descriptor (u32): bits 0..15 = offset of the table in the slot (u16 entries), bits 16..19
@@ -321,16 +354,6 @@ DEV void build_table(Hdr &h, const Cnt16 &count)
  * P(L) = E(L) >> (L - root) hold no code longer than L.  All sizes follow from count[] alone, so
  * the table is laid out before a single entry is written, and every lane can place its own
  * symbols (construct(): yeast.c:246-278 gives the canonical order the ranks below reproduce). */
-DEV void cnt_set(Cnt16 &k, u32 i, u32 v)
-{
-    u64 m = (u64)0xffff << ((i & 3) * 16), x = (u64)v << ((i & 3) * 16);
-    u32 q = i >> 2;
-    k.q0 = q == 0 ? (k.q0 & ~m) | x : k.q0;
-    k.q1 = q == 1 ? (k.q1 & ~m) | x : k.q1;
-    k.q2 = q == 2 ? (k.q2 & ~m) | x : k.q2;
-    k.q3 = q == 3 ? (k.q3 & ~m) | x : k.q3;
-}
-
 /* nz: the coded symbols as (length << 12 | symbol), ascending symbols within each length */
 DEV void build_table_lds(Hdr &h, const Cnt16 &count, const u16 *nz, u32 nnz, u32 rootcap)
 {
@@ -457,9 +480,11 @@ DEV u32 dec_sym_lds(Rd &r, LAS const u16 *slot, u32 desc)
     return e >> 4;
 }
 
-DEV u32 rootcap_of(const Hdr &h, u32 num)
+/* root width of the table about to be built: h.kind says what the code is for */
+enum { YS_KIND_OTHER = 0, YS_KIND_LIT = 1, YS_KIND_IAC = 2, YS_KIND_DIST = 3 };
+DEV u32 rootcap_of(const Hdr &h)
 {
-    return num == 256 ? h.rootcaps & 255 : num == 704 ? (h.rootcaps >> 8) & 255 : (h.rootcaps >> 16) & 255;
+    return (h.rootcaps >> (8 * h.kind)) & 255;
 }
 
 /* read_code(): prefix() yeast.c:361-542.  num = alphabet size.  Leaves the
@@ -520,11 +545,11 @@ NOINL Hdr read_code_t(Hdr h, u32 num)
             gst16(nz + 2, (((sl >> 8) & 15) << 12) | s2);
             gst16(nz + 3, (((sl >> 12) & 15) << 12) | s3);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            build_table_lds(h, count, nz, shape > 4 ? 4 : shape, rootcap_of(h, num));
+            build_table_lds(h, count, nz, shape > 4 ? 4 : shape, rootcap_of(h));
             return h;
         }
         gst16(sorted, s0); gst16(sorted + 1, s1); gst16(sorted + 2, s2); gst16(sorted + 3, s3);
-        build_table(h, count);
+        build_table(h, count, rootcap_of(h));
         return h;
     }
 
@@ -666,7 +691,7 @@ NOINL Hdr read_code_t(Hdr h, u32 num)
 
     if (h.lds) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        build_table_lds(h, count, nz, nnz, rootcap_of(h, num));
+        build_table_lds(h, count, nz, nnz, rootcap_of(h));
         return h;
     }
     /* counting sort into canonical order (construct() yeast.c:266-277) */
@@ -687,7 +712,7 @@ NOINL Hdr read_code_t(Hdr h, u32 num)
         cnt_add(offs, l, 1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    build_table(h, count);
+    build_table(h, count, rootcap_of(h));
     return h;
 }
 

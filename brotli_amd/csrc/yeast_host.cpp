@@ -26,6 +26,9 @@ int ys_upload_constants(const u8 *lut768);
 int ys_upload_check_constants(const u32 *x2n);
 int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned groups, void *stream);
 int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, int half, unsigned groups, void *stream);
+int ysl_upload_constants(const u8 *lut768);
+int ysl_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base, u8 *xdict, void *stream);
+int ysl_launch(const ys_params *p, int half, unsigned streams, void *stream);
 int ysw_upload_constants(const u8 *lut768);
 unsigned ysw_shared_bytes(void);
 int ysw_launch(const ys_params *p, unsigned slot_entries, unsigned rootcaps, unsigned blocks, void *stream);
@@ -117,6 +120,8 @@ struct Buf {
 struct Device {
     bool ready = false;
     u8 *d_dict = nullptr, *d_xf = nullptr;
+    u8 *d_xdict = nullptr;   /* every transform of every dictionary word, ~19 MB (yeast_lane.hip k_expand_dict) */
+    u32 *d_xbase = nullptr;  /* [121][21] offsets into it */
     int cus = 256;
     Buf src, dst, soff, doff, rec, ws, ws_big, ctr, scratch;
 };
@@ -160,6 +165,8 @@ static int device_get(Device **out)
             x2n[k] = crc_mul(x2n[k - 1], x2n[k - 1]);
         int e = ys_upload_constants(g_luts);
         if (!e)
+            e = ysl_upload_constants(g_luts);
+        if (!e)
             e = ysw_upload_constants(g_luts);
         if (!e)
             e = ys_upload_check_constants(x2n);
@@ -170,6 +177,30 @@ static int device_get(Device **out)
         HIPCK(hipMalloc((void **)&d.d_xf, 4096));
         HIPCK(hipMemcpy(d.d_dict, ys_dictionary, sizeof(ys_dictionary), hipMemcpyHostToDevice));
         HIPCK(hipMemcpy(d.d_xf, ys_transforms, sizeof(ys_transforms), hipMemcpyHostToDevice));
+        {
+            /* layout of the expanded dictionary: for each transform and word length the entries
+               (prefix + transformed word + suffix, a fixed size per pair) lie back to back */
+            static const u8 ndbits[25] = {0, 0, 0, 0, 10, 10, 11, 11, 10, 10, 10, 10, 10, 9, 9, 8, 7, 7, 8, 7, 7, 6, 6, 5, 5};
+            std::vector<u32> base(121 * 21);
+            u64 total = 0;
+            for (u32 t = 0; t < 121; t++) {
+                const u8 *rec = ys_transforms + 20 * t;
+                u32 op = rec[0], omit = rec[1], plen = rec[2], slen = rec[3];
+                for (u32 L = 4; L <= 24; L++) {
+                    u32 wlen = (op == 3 || op == 4) ? (L > omit ? L - omit : 0) : L;
+                    base[t * 21 + L - 4] = (u32)total;
+                    total += (u64)(plen + wlen + slen) << ndbits[L];
+                }
+            }
+            HIPCK(hipMalloc((void **)&d.d_xdict, total + 64));
+            HIPCK(hipMemset(d.d_xdict, 0, total + 64));
+            HIPCK(hipMalloc((void **)&d.d_xbase, base.size() * 4));
+            HIPCK(hipMemcpy(d.d_xbase, base.data(), base.size() * 4, hipMemcpyHostToDevice));
+            e = ysl_expand_dict(d.d_dict, d.d_xf, d.d_xbase, d.d_xdict, nullptr);
+            if (e)
+                return fail("dictionary expansion", (hipError_t)e);
+            HIPCK(hipDeviceSynchronize());
+        }
         hipDeviceProp_t prop;
         HIPCK(hipGetDeviceProperties(&prop, id));
         d.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -249,6 +280,8 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     p.n = (u32)n;
     p.dict = d.d_dict;
     p.xforms = d.d_xf;
+    p.xdict = d.d_xdict;
+    p.xdict_base = d.d_xbase;
     int e;
     if (lanes == YS_LANES_WAVE) {
         /* one wavefront per stream, tables in LDS: blocks of four wavefronts; the LDS of a CU is
@@ -265,9 +298,9 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
             lds_per_block = 64u * 1024u;
         unsigned slot_entries = ((lds_per_block - ysw_shared_bytes() - 64) / 4 / 2) & ~7u;
         slot_entries = (unsigned)env_int("YEAST_SLOT_ENTRIES", (int)slot_entries);
-        /* root table widths: literal | insert-and-copy << 8 | others << 16 */
-        unsigned rootcaps = (unsigned)env_int("YEAST_ROOT_LIT", 7) | ((unsigned)env_int("YEAST_ROOT_IAC", 8) << 8) |
-                            ((unsigned)env_int("YEAST_ROOT_OTHER", 8) << 16);
+        /* widest root tables: other | literal << 8 | insert-and-copy << 16 | distance << 24 */
+        unsigned rootcaps = 8u | ((unsigned)env_int("YEAST_ROOT_LIT", 7) << 8) | ((unsigned)env_int("YEAST_ROOT_IAC", 8) << 16) |
+                            ((unsigned)env_int("YEAST_ROOT_DIST", 8) << 24);
         size_t want = (n + 3) / 4, maxb = (size_t)d.cus * blocks_per_cu;
         unsigned blocks = (unsigned)(want < maxb ? want : maxb);
         u64 stride = 32768; /* header scratch per wavefront: yeast_wave.hip w_metablock() */
@@ -299,7 +332,19 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         return -1;
     p.ws = (u8 *)d.ws.p;
     p.ws_stride = stride;
-    e = flat ? ys_launch_decode_flat(&p, lanes, half, groups, st) : ys_launch_decode(&p, lanes, cmp, groups, st);
+    if (env_int("YEAST_EXP_SHARED_WS", 0))
+        p.ws_stride = 0; /* experiment (identical streams only): every stream uses the same table memory */
+    if (lanes == 1 && !env_int("YEAST_FLAT_OLD", 0)) {
+        /* the lean loop (yeast_lean.h); narrow root tables keep the tables of all resident streams
+           in the Infinity Cache */
+        unsigned rl = (unsigned)env_int("YEAST_LEAN_ROOT_LIT", 6), ri = (unsigned)env_int("YEAST_LEAN_ROOT_IAC", 8),
+                 rd = (unsigned)env_int("YEAST_LEAN_ROOT_DIST", 6);
+        auto clamp = [](unsigned v) { return v < 4 ? 4u : v > 8 ? 8u : v; };
+        p.rootcaps = 8u | (clamp(rl) << 8) | (clamp(ri) << 16) | (clamp(rd) << 24);
+        e = ysl_launch(&p, half, groups, st);
+    }
+    else
+        e = flat ? ys_launch_decode_flat(&p, lanes, half, groups, st) : ys_launch_decode(&p, lanes, cmp, groups, st);
     if (e)
         return fail("decode launch", (hipError_t)e);
     }
@@ -312,6 +357,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     p.ws_stride = YS_WS_MAX;
     p.counter = (u32 *)d.ctr.p + 1;
     p.retry = 1;
+    p.rootcaps = 0;
     e = ys_launch_decode(&p, 64, cmp, big_groups, st);
     if (e)
         return fail("retry launch", (hipError_t)e);

@@ -1,0 +1,86 @@
+/*
+ * yeast_lane.hip -- MI355X (gfx950) batch Brotli decode, one stream per lane: the kernel of large
+ * batches (BASELINE config 2).  The per-stream decoder is yeast_stream.h, its command loop
+ * yeast_lean.h; this file holds the kernel, the kernel that expands the static dictionary, and
+ * their launchers.
+ */
+#include <hip/hip_runtime.h>
+#include "yeast_stream.h"
+
+/* Every stream of a wavefront starts at the same time, so header parsing, the command loop and the
+   record write-out run converged across the S streams of the wavefront; a wavefront takes the
+   next S streams when all of its streams are done.  S = 64 fills the wavefront; S = 32 leaves the
+   upper half idle so that two wavefronts fit each SIMD and one's memory latency hides behind the
+   other's work. */
+template <int S>
+__global__ __launch_bounds__(256, 64 / S) void k_decode_lean(ys_params p)
+{
+    __shared__ Shared sh;
+    __shared__ LeanLds<S> wlds[4];
+    shared_fill(sh, p.xforms, p.xdict_base);
+    u32 lane = threadIdx.x;
+    u32 wave = (blockIdx.x * blockDim.x + lane) >> 6;
+    u32 slot = lane & 63;
+    u8 *ws = p.ws + (u64)(wave * S + (slot < S ? slot : 0)) * p.ws_stride;
+    const u32 limit = p.retry ? *p.retry_count : p.n;
+    for (;;) {
+        u32 base = 0;
+        if ((lane & 63) == 0)
+            base = atomicAdd(p.counter, (u32)S);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= limit)
+            break;
+        u32 job = base + slot;
+        if (slot < S && job < limit) {
+            if (p.retry)
+                job = p.retry_list[job];
+            decode_stream<1, false, 1000 + S>(p, job, ws, &sh, 0, &wlds[lane >> 6]);
+        }
+    }
+}
+
+/* The expanded dictionary: entry (transform t, word length L, index i) is dict_word() of
+   yeast.c:908-949 for id = t << NDBITS[L] | i, written with the same code the decode kernels use.
+   One thread per entry; entries of one (t, L) lie back to back from base[t][L - 4]. */
+__global__ __launch_bounds__(256) void k_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base, u8 *xdict)
+{
+    __shared__ Shared sh;
+    shared_fill(sh, xforms, base);
+    u32 t = blockIdx.y;
+    Ctx c;
+    c.dict = dict;
+    c.xf = xforms;
+    c.sh = &sh;
+    for (u32 L = 4; L <= 24; L++) {
+        u32 nd = sh.dict[L] >> 24;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << nd); i += gridDim.x * blockDim.x) {
+            DictRef d;
+            if (!dict_prepare(c, L, ((u64)t << nd) | i, d))
+                continue;
+            dict_write_exact(d, xdict + sh.xbase[t * YS_XD_LENS + L - 4] + i * d.total);
+        }
+    }
+}
+
+extern "C" int ysl_upload_constants(const u8 *lut768) { return ys_upload_constants_impl(lut768); }
+
+extern "C" int ysl_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base, u8 *xdict, void *stream)
+{
+    hipLaunchKernelGGL(k_expand_dict, dim3(4, 121), dim3(256), 0, (hipStream_t)stream, dict, xforms, base, xdict);
+    return (int)hipGetLastError();
+}
+
+template <int S>
+static int launch_lean_t(const ys_params &p, u32 streams, hipStream_t st)
+{
+    u32 per_block = 4 * S;
+    u32 blocks = (streams + per_block - 1) / per_block;
+    hipLaunchKernelGGL((k_decode_lean<S>), dim3(blocks), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+
+/* streams = resident streams (each owns one workspace slot); half != 0: half-filled wavefronts */
+extern "C" int ysl_launch(const ys_params *p, int half, unsigned streams, void *stream)
+{
+    return half ? launch_lean_t<32>(*p, streams, (hipStream_t)stream) : launch_lean_t<64>(*p, streams, (hipStream_t)stream);
+}

@@ -680,6 +680,7 @@ DEV u32 w_metablock(WCtx &c, const WConst &K)
     h.lds_used = 0;
     h.lds_size = c.slot_entries;
     h.rootcaps = c.rootcaps;
+    h.kind = YS_KIND_OTHER;
     w_block_header(h, c.L);
     w_block_header(h, c.I);
     w_block_header(h, c.D);
@@ -714,16 +715,19 @@ DEV u32 w_metablock(WCtx &c, const WConst &K)
     LAS u32 *itab = (LAS u32 *)(c.slot + env.o_itab);
     LAS u32 *dtab = (LAS u32 *)(c.slot + env.o_dtab);
     env.descL0 = env.descD0 = 0;
+    h.kind = YS_KIND_LIT;
     for (n = 0; n < c.lit_codes && !h.r.rc; n++) {
         w_code(h, 256);
         gst32(ldir + n, h.tab);
         env.descL0 = n ? env.descL0 : h.tab;
     }
+    h.kind = YS_KIND_IAC;
     for (n = 0; n < c.I.num && !h.r.rc; n++) {
         w_code(h, 704);
         if (c.lane == 0)
             itab[n] = h.tab;
     }
+    h.kind = YS_KIND_DIST;
     for (n = 0; n < c.dist_codes && !h.r.rc; n++) {
         w_code(h, dists);
         gst32(ddir + n, h.tab);

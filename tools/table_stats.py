@@ -102,3 +102,36 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def second_level_share():
+    """share of lookups that need a second level, by alphabet and root width, if symbols occur
+    with probability 2^-length"""
+    name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_streams"
+    meta, streams = H.packed_streams(name)
+    L = H.oracle()
+    cap = 4096
+    log = (ctypes.c_uint16 * (17 * cap))()
+    ctypes.c_void_p.in_dll(L, "oracle_code_log").value = ctypes.addressof(log)
+    ctypes.c_size_t.in_dll(L, "oracle_code_log_cap").value = cap
+    acc = {}
+    for s in streams:
+        ctypes.c_size_t.in_dll(L, "oracle_code_log_n").value = 0
+        H.oracle_yeast(s)
+        n = ctypes.c_size_t.in_dll(L, "oracle_code_log_n").value
+        codes = np.frombuffer(log, dtype=np.uint16, count=17 * n).reshape(n, 17)
+        for c in codes:
+            num = int(c[0])
+            kind = "literal" if num == 256 else "iac" if num == 704 else "dist" if 64 <= num <= 520 else None
+            if kind is None:
+                continue
+            cnt = c[1:].astype(np.float64)
+            for R in (4, 5, 6, 7, 8):
+                p = sum(cnt[l] * 2.0 ** -l for l in range(R + 1, 16))
+                acc.setdefault((kind, R), []).append(p)
+    for k in sorted(acc):
+        print("%-8s root %d: second-level share mean %.3f  max %.3f" % (k[0], k[1], np.mean(acc[k]), np.max(acc[k])))
+
+
+if __name__ == "__main__" and os.environ.get("SECOND"):
+    second_level_share()
