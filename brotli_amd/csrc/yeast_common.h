@@ -14,6 +14,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int64_t i64;
+typedef int32_t i32;
 
 /* Per-stream status.  0..4 are the reference's return codes (yeast.h:13-22);
    5 and 6 never leave the library through yeast(): the host retries. */

@@ -2,24 +2,26 @@
  * yeast_lean.h -- the command loop of the batch kernel, one stream per lane (included by
  * yeast_stream.h; reference: the loop of yeast.c:1166-1295).
  *
- * Every trip of the loop decodes at most one prefix-code symbol per stream, so the streams that
- * share a wavefront meet at the one table lookup of the trip whatever they are decoding:
- * insert-and-copy, literal, distance, block type or block count.  What a trip does besides the
- * lookup is kept short:
+ * One pass of the loop takes every stream of the wavefront through the phases of a command in
+ * the order the format puts them: (A) the insert-and-copy symbol with its extra bits, (B) a
+ * literal, twice, (C) the distance symbol, (D) the copy.  A stream takes part in a phase when it
+ * is at that point of its command, so a stream whose command has no literals goes through a whole
+ * command per pass and the instructions of a phase always serve most of the lanes; streams in a
+ * long run of literals use only the (B) phases, streams in a long copy only (D).  Each decoding
+ * phase has one table lookup and waits for memory once.
  *
- *   - one place where the wavefront waits for memory: the lookup, the two prefetched input words
- *     and the copy bytes requested on the previous trip all arrive there (every table offset the
- *     loop needs is in LDS or in a register; only a block switch reloads some from memory);
- *   - bytes are moved by a small per-stream copy engine: a trip that reaches a copy (or is in the
- *     middle of a long one) sets up a piece of up to 32 bytes; the next trip fetches it together
- *     with its lookup and stores it.  The command symbol that always lies between a copy and the next literal gives that
- *     trip for free, so literal contexts never wait.  Overlapping copies (byte-serial semantics of
+ *   - bytes are moved by a small per-stream copy engine: phase (D) sets up a piece of up to 32
+ *     bytes; the next pass fetches it together with the phase (A) lookup and stores it.  Literal
+ *     contexts after a copy therefore never wait.  Overlapping copies (byte-serial semantics of
  *     yeast.c:1285-1293) go in pieces no longer than their period, the period doubling with every
- *     whole period written; periods below 8 bytes are expanded in registers;
+ *     whole period written;
  *   - static dictionary words are copies too: the source is the table of all 121 transforms of
  *     all words (ys_params.xdict, built on the device at start-up by k_expand_dict from
  *     dict_word(): yeast.c:908-949), so no transform is evaluated here;
- *   - literals go straight to the output region.
+ *   - literals go straight to the output region;
+ *   - the second half of a code longer than its root table is looked up on the next pass;
+ *   - a block switch (type code, count code, reload of the new type's table offsets) is a rare
+ *     phase of its own at the head of the pass.
  */
 #ifndef YEAST_LEAN_H
 #define YEAST_LEAN_H
@@ -38,9 +40,9 @@ struct LeanLds {
 template <int S, bool SIMPLE> /* SIMPLE: no stream of the wavefront switches block types */
 DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
 {
-    enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3, ST_BT = 4, ST_BC = 5, ST_COPY = 6, ACT_NONE = 7 };
+    enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3, ST_BSW = 4, ST_COPY = 6, ST_START = 7 };
     Rd &r = c.r;
-    LeanLds<S> *wl = (LeanLds<S> *)c.wl;
+    LAS LeanLds<S> *wl = (LAS LeanLds<S> *)c.wl;
     const u32 slot = threadIdx.x & 63;
     const bool ctx = fe.ctx;
     const u64 *cmd_tab = c.sh->cmd;
@@ -75,22 +77,23 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
         left2 = c.D.left;
     }
     u32 st, cat = 0; /* cat: the state a block switch returns to */
-    u32 off = 0, link = 0;
+    u32 link = 0;    /* first half of a long code of the state the stream is in */
     u32 insert = 0, copy = 0, implicit = 0;
+    i32 dist = 0;
     u64 got0 = got_of(c);
     u32 maxd = got0 > c.wsize ? c.wsize : (u32)got0;
-    /* input: the window r.w and the next two words, requested a trip ahead */
+    /* input: the window r.w and the next two words, requested ahead of their use */
     u32 q0 = r.nxt, q1 = 0, nq = 1; /* q0 = word r.idx of the stream, q1 the one after it */
     /* copy engine */
-    const u8 *psrc = c.outp; /* the piece set up on the previous trip: fetched and stored on this one */
+    const u8 *psrc = c.outp; /* the piece set up on the previous pass: fetched and stored on this one */
     u8 *pdst = c.outp;
-    u32 pn = 0, pmode = 0; /* its bytes; period (1..7) of a short-period piece, else 0 */
-    u32 psafe = 0;         /* it lies at the very end of the output region: nothing is read beyond it */
+    u32 pn = 0;    /* its bytes */
+    u32 psafe = 0; /* it lies at the very end of the output region: nothing is read or written beyond it */
     const u8 *csrc = c.outp;
     u32 crem = 0, cD = 0; /* copy in progress: bytes left, period limit */
 
-    /* move the next word into the window (both queued words have arrived by the time this runs,
-       except after three refills within two trips: then the word is fetched on the spot) */
+    /* move the next word into the window (the queued words have arrived by the time this runs,
+       except after a third refill between two requests: then the word is fetched on the spot) */
     auto refill = [&]() {
         if (r.have <= 32) {
             if (nq == 0) {
@@ -108,18 +111,72 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             }
         }
     };
-    auto bits_mid = [&](u32 n, u32 &act) -> u32 {
+    auto top_up = [&]() {
+        if (nq == 0)
+            q0 = gld32(r.p + r.idx);
+        if (nq < 2)
+            q1 = gld32(r.p + r.idx + 1);
+        nq = 2;
+    };
+    auto bits_mid = [&](u32 n, bool &ok) -> u32 {
         if (n > r.have)
             refill();
         if (n > r.have) {
             rd_eof(r);
             n = 0;
-            act = ACT_NONE;
+            ok = false;
         }
         u32 v = (u32)r.w & ((1u << n) - 1);
         r.w >>= n;
         r.have -= n;
         return v;
+    };
+    /* the lookup of a phase: request the entry for the streams that take part */
+    auto lookup = [&](bool on, u32 off, u32 root) -> u32 {
+        if (on)
+            refill();
+        top_up();
+        u32 e = 0;
+        if (on) {
+            u32 peek = (u32)r.w;
+            u32 idx = link ? (link >> 4) + ((peek >> root) & ((1u << ((link & 15) - root)) - 1)) : (peek & ((1u << root) - 1));
+            e = gld16((const u16 *)(ws + off) + idx);
+        }
+        return e;
+    };
+    /* consume the code; false: nothing decoded (first half of a long code, or the input ran out) */
+    auto decode = [&](bool on, u32 e, u32 root) -> bool {
+        u32 l = e & 15;
+        bool first_half = on && !link && l > root;
+        link = on ? (first_half ? e : 0) : link;
+        bool ok = on && !first_half;
+        l = ok ? l : 0;
+        if (l > r.have) {
+            rd_eof(r);
+            l = 0;
+            ok = false;
+        }
+        r.w >>= l;
+        r.have -= l;
+        return ok;
+    };
+    /* a whole symbol at once, both levels (block switches only) */
+    auto decode_now = [&](u32 off) -> u32 {
+        refill();
+        u32 peek = (u32)r.w;
+        u32 e = gld16((const u16 *)(ws + off) + (peek & 255));
+        u32 l = e & 15;
+        if (l > ROOT) {
+            e = gld16((const u16 *)(ws + off) + (e >> 4) + ((peek >> ROOT) & ((1u << (l - ROOT)) - 1)));
+            l = e & 15;
+        }
+        if (l > r.have) {
+            rd_eof(r);
+            l = 0;
+        }
+        r.w >>= l;
+        r.have -= l;
+        return e >> 4;
     };
     /* move to a symbol state; a used-up block count turns it into a block switch first
        (yeast.c:1168-1180, 1192-1204, 1239-1251) */
@@ -129,7 +186,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             if ((num3 >> (8 * s)) & 255) {
                 u32 left = s == 0 ? left0 : s == 1 ? left1 : left2;
                 if (left == 0) {
-                    st = ST_BT;
+                    st = ST_BSW;
                     cat = s;
                 }
                 left0 -= s == 0 && left;
@@ -138,196 +195,25 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             }
         }
     };
-    /* the pieces requested on the previous trip go to the output region */
-    auto store_pending = [&](u64 a0, u64 a1, u64 a2, u64 a3) {
-        if (pmode) { /* period below 8: byte i of the piece is byte i mod period of the source */
-            u32 d = pmode;
-            u64 pat = a0 & ~(~0ull << (8 * d));
-            pat |= d < 8 ? pat << (8 * d) : 0;
-            pat |= 2 * d < 8 ? pat << (16 * d) : 0;
-            pat |= 4 * d < 8 ? pat << (32 * d) : 0;
-            u32 r1 = (0x1230200u >> (4 * (d - 1))) & 15; /* 8 mod d */
-            u32 r2 = 2 * r1 >= d ? 2 * r1 - d : 2 * r1;
-            u32 r3 = r2 + r1 >= d ? r2 + r1 - d : r2 + r1;
-            a0 = pat;
-            a1 = (pat >> (8 * r1)) | (pat << (8 * (d - r1)));
-            a2 = (pat >> (8 * r2)) | (pat << (8 * (d - r2)));
-            a3 = (pat >> (8 * r3)) | (pat << (8 * (d - r3)));
-        }
-        if (pdst + ((pn + 7) & ~7u) <= out_end) { /* whole units; the excess is overwritten by what follows */
-            gst64u(pdst, a0);
-            if (pn > 8)
-                gst64u(pdst + 8, a1);
-            if (pn > 16)
-                gst64u(pdst + 16, a2);
-            if (pn > 24)
-                gst64u(pdst + 24, a3);
-        } else { /* the last bytes of the output region: exact */
-            put_le(pdst, a0, pn);
-            if (pn > 8)
-                put_le(pdst + 8, a1, pn - 8);
-            if (pn > 16)
-                put_le(pdst + 16, a2, pn - 16);
-            if (pn > 24)
-                put_le(pdst + 24, a3, pn - 24);
-        }
-        if (ctx) { /* the last two bytes written: literal context of what follows (without
-                      context modelling they are read back at the end of the meta-block) */
-            u32 k1 = pn - 1, q = k1 >> 3;
-            u64 x1 = q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : a3;
-            u32 b1 = (u32)(x1 >> (8 * (k1 & 7))) & 255;
-            u32 b2 = c.p1;
-            if (pn >= 2) {
-                u32 k2 = pn - 2;
-                q = k2 >> 3;
-                u64 x2 = q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : a3;
-                b2 = (u32)(x2 >> (8 * (k2 & 7))) & 255;
-            }
-            c.p1 = b1;
-            c.p2 = b2;
-        }
-        pn = 0;
-    };
 
     /* nothing loaded above is still on its way when the loop starts (a wait placed inside the loop
-       for the first trip's sake would be paid on every trip) */
+       for the first pass's sake would be paid on every pass) */
     asm volatile("" : "+v"(offI), "+v"(offL), "+v"(offD), "+v"(cur_mode), "+v"(q0));
     enter(ST_CMD);
     while (st != ST_END) {
-        const bool look = st != ST_COPY;
-        u32 root = st == ST_LIT ? rootL : st == ST_CMD ? rootI : rootD;
-        if (!link) {
-            off = st == ST_CMD ? offI : st == ST_LIT ? offL : offD;
-            if (!SIMPLE) {
-                if (st == ST_BT)
-                    off = cat == ST_CMD ? c.I.t_type : cat == ST_LIT ? c.L.t_type : c.D.t_type;
-                else if (st == ST_BC)
-                    off = cat == ST_CMD ? c.I.t_count : cat == ST_LIT ? c.L.t_count : c.D.t_count;
-            }
-        }
-        if (!SIMPLE)
-            root = st == ST_BT || st == ST_BC ? (u32)ROOT : root;
-        /* ---- the one table lookup of this trip, and the input words after the queued ones ---- */
-        refill();
-        u32 peek = (u32)r.w;
-        u32 idx = link ? (link >> 4) + ((peek >> root) & ((1u << ((link & 15) - root)) - 1)) : (peek & ((1u << root) - 1));
-        /* every load of the trip is issued here, and waited for once */
-        u64 pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0;
-        if (pn) {
-            if (psafe) {
-                for (u32 b = 0; b < pn; b++)
-                    pd0 |= (u64)gld8(psrc + b) << (8 * b);
-            } else {
-                pd0 = gld64u(psrc);
-                if (pn > 8 && !pmode)
-                    pd1 = gld64u(psrc + 8);
-                if (pn > 16 && !pmode)
-                    pd2 = gld64u(psrc + 16);
-                if (pn > 24 && !pmode)
-                    pd3 = gld64u(psrc + 24);
-            }
-        }
-        if (nq == 0)
-            q0 = gld32(r.p + r.idx);
-        if (nq < 2)
-            q1 = gld32(r.p + r.idx + 1);
-        nq = 2;
-        u32 e = 0;
-        if (look)
-            e = gld16((const u16 *)(ws + off) + idx);
-        asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1), "+v"(pd0), "+v"(pd1), "+v"(pd2), "+v"(pd3));
-
-        if (pn)
-            store_pending(pd0, pd1, pd2, pd3);
-
-        u32 l = e & 15;
-        bool first_half = look && !link && l > root;
-        link = first_half ? e : 0;
-        l = first_half || !look ? 0 : l;
-        u32 act = first_half ? (u32)ACT_NONE : st;
-        if (l > r.have) {
-            rd_eof(r);
-            l = 0;
-            act = ACT_NONE;
-        }
-        r.w >>= l;
-        r.have -= l;
-        const u32 sym = e >> 4;
-
-        bool start_copy = false;
-        i64 dist = c.r0;
-        if (act == ST_LIT) {
-            gst8(c.outp, sym);
-            c.outp++;
-            maxd = maxd < c.wsize ? maxd + 1 : maxd;
-            c.p2 = c.p1;
-            c.p1 = sym;
-            if (--insert == 0) {
-                if (mlen == 0)
-                    st = ST_END; /* :1227 */
-                else if (implicit)
-                    start_copy = true;
-                else
-                    enter(ST_DIST);
-            } else
-                enter(ST_LIT);
-        } else if (act == ST_CMD) {
-            u64 ce = cmd_tab[sym < 704 ? sym : 0];
-            u32 x1 = bits_mid(((u32)ce >> 16) & 0xff, act);
-            u32 x2 = bits_mid((u32)(ce >> 40), act);
-            if (act == ST_CMD) {
-                insert = ((u32)ce & 0xffff) + x1;
-                copy = ((u32)(ce >> 24) & 0xffff) + x2;
-                implicit = sym < 128;
-                if (insert > mlen) {
-                    rd_fail(r, YS_INVALID); /* :1189 */
-                    insert = 0;
-                }
-                mlen -= insert;
-                if (insert)
-                    enter(ST_LIT);
-                else if (implicit)
-                    start_copy = true;
-                else
-                    enter(ST_DIST);
-            }
-        } else if (act == ST_DIST) { /* distance(): yeast.c:761-789 */
-            u32 ds = sym;
-            if (ds < 16) {
-                u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
-                u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
-                u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
-                int dl = (int)(k >> 1) + 1;
-                dl = (k & 1) ? dl : -dl;
-                dl = ds < 4 ? 0 : dl;
-                dist = (i64)rv + dl;
-            } else if (ds < 16 + c.direct)
-                dist = ds - 15;
-            else {
-                u32 dn = ds - c.direct - 16;
-                u32 dx = 1 + (dn >> (c.postfix + 1));
-                dx = dx > 25 ? 25 : dx; /* only after a read failure */
-                u32 x1 = bits_mid(dx, act);
-                u64 o2 = ((u64)(2 + ((dn >> c.postfix) & 1)) << dx) - 4;
-                dist = (i64)(((o2 + x1) << c.postfix) + (dn & ((1u << c.postfix) - 1)) + c.direct + 1);
-            }
-            if (act == ST_DIST) {
-                if (ds && dist > 0 && dist <= (i64)maxd) {
-                    c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
-                }
-                start_copy = true;
-            }
-        } else if (!SIMPLE && act == ST_BT) { /* block switch, type code: yeast.c:1168-1180 */
+        /* ---- block switch (rare): type code, count code, the new type's tables ---- */
+        if (!SIMPLE && st == ST_BSW) {
             u32 sh = 8 * cat;
+            u32 t_type = cat == ST_CMD ? c.I.t_type : cat == ST_LIT ? c.L.t_type : c.D.t_type;
+            u32 t_count = cat == ST_CMD ? c.I.t_count : cat == ST_LIT ? c.L.t_count : c.D.t_count;
+            u32 sym = decode_now(t_type);
             u32 k_type = (type3 >> sh) & 255, k_num = ((num3 >> sh) & 255) + 1, k_prev = (prev3 >> sh) & 255;
             u32 n = sym > 1 ? sym - 2 : sym ? (k_type + 1 == k_num ? 0 : k_type + 1) : k_prev;
             if (n >= k_num)
                 n = 0; /* only reachable after a read failure; keeps table indices in range */
             prev3 = (prev3 & ~(255u << sh)) | (k_type << sh);
             type3 = (type3 & ~(255u << sh)) | (n << sh);
-            st = ST_BC;
-        } else if (!SIMPLE && act == ST_BC) { /* and the new block's count: block_length() yeast.c:550-567 */
-            u32 s = sym, base, extra;
+            u32 s = decode_now(t_count), base, extra; /* block_length(): yeast.c:550-567 */
             if (s < 4) { base = 1 + 4 * s; extra = 2; }
             else if (s < 8) { base = 17 + 8 * (s - 4); extra = 3; }
             else if (s < 12) { base = 49 + 16 * (s - 8); extra = 4; }
@@ -335,50 +221,193 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             else if (s < 18) { base = 241 + 64 * (s - 16); extra = 6; }
             else if (s >= 25) { base = 16625; extra = 24; }
             else { extra = s - 11; base = 369 + ((1u << (s - 11)) - 128); }
-            u32 x = bits_mid(extra, act);
-            if (act == ST_BC) {
-                u32 left = base + x - 1; /* the symbol that follows is the block's first */
-                u32 type = (type3 >> (8 * cat)) & 255;
-                /* the new type's table offsets come from memory: the one place besides the lookup
-                   where a trip waits for it (block switches are rare) */
-                if (cat == ST_CMD) {
-                    left0 = left;
-                    offI = gld32(fe.itab + type);
-                } else if (cat == ST_LIT) {
-                    left1 = left;
-                    cur_mode = gld8(fe.mode + type);
-                    if (ctx)
-                        load_lt(type);
-                } else {
-                    left2 = left;
-                    if (c.dist_codes > 1)
-                        load_dt(type);
-                }
-                st = cat;
+            bool ok = true;
+            u32 left = base + bits_mid(extra, ok) - 1; /* the symbol that follows is the block's first */
+            if (cat == ST_CMD) {
+                left0 = left;
+                offI = gld32(fe.itab + n);
+            } else if (cat == ST_LIT) {
+                left1 = left;
+                cur_mode = gld8(fe.mode + n);
+                if (ctx)
+                    load_lt(n);
+            } else {
+                left2 = left;
+                if (c.dist_codes > 1)
+                    load_dt(n);
             }
+            st = r.rc ? (u32)ST_END : cat;
+            asm volatile("" : "+v"(offI), "+v"(cur_mode), "+v"(q0), "+v"(q1));
         }
 
-        /* ---- a copy begins: where its bytes come from ---- */
-        if (start_copy && !r.rc) {
+        /* ---- (A) the piece set up on the last pass, and the insert-and-copy symbol ---- */
+        {
+            u64 pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0;
+            u32 pe = 0;
+            if (pn) {
+                if (psafe) {
+                    for (u32 b = 0; b < pn; b++)
+                        pd0 |= (u64)gld8(psrc + b) << (8 * b);
+                } else {
+                    pd0 = gld64u(psrc);
+                    if (pn > 8)
+                        pd1 = gld64u(psrc + 8);
+                    if (pn > 16)
+                        pd2 = gld64u(psrc + 16);
+                    if (pn > 24)
+                        pd3 = gld64u(psrc + 24);
+                    if (pn >= 2)
+                        pe = gld16u(psrc + pn - 2);
+                }
+            }
+            const bool on = st == ST_CMD;
+            u32 e = lookup(on, offI, rootI);
+            asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1), "+v"(pd0), "+v"(pd1), "+v"(pd2), "+v"(pd3), "+v"(pe));
+            if (pn) {
+                if (psafe) { /* the last bytes of the output region: exact */
+                    for (u32 b = 0; b < pn; b++)
+                        gst8(pdst + b, (u32)(pd0 >> (8 * b)) & 255);
+                    pe = pn >= 2 ? (u32)(pd0 >> (8 * (pn - 2))) & 0xffff : 0;
+                } else { /* whole units; the excess is overwritten by what follows */
+                    gst64u(pdst, pd0);
+                    if (pn > 8)
+                        gst64u(pdst + 8, pd1);
+                    if (pn > 16)
+                        gst64u(pdst + 16, pd2);
+                    if (pn > 24)
+                        gst64u(pdst + 24, pd3);
+                }
+                /* the last two bytes written: literal context of what follows */
+                u32 b2 = pn >= 2 ? pe & 255 : c.p1;
+                u32 b1 = pn >= 2 ? pe >> 8 : (u32)pd0 & 255;
+                c.p1 = b1;
+                c.p2 = b2;
+                pn = 0;
+            }
+            bool ok = decode(on, e, rootI);
+            if (ok) {
+                u32 sym = e >> 4;
+                u64 ce = cmd_tab[sym < 704 ? sym : 0];
+                u32 x1 = bits_mid(((u32)ce >> 16) & 0xff, ok);
+                u32 x2 = bits_mid((u32)(ce >> 40), ok);
+                if (ok) {
+                    insert = ((u32)ce & 0xffff) + x1;
+                    copy = ((u32)(ce >> 24) & 0xffff) + x2;
+                    implicit = sym < 128;
+                    if (insert > mlen) {
+                        rd_fail(r, YS_INVALID); /* :1189 */
+                        insert = 0;
+                    }
+                    mlen -= insert;
+                    dist = (i32)c.r0;
+                    if (insert)
+                        enter(ST_LIT);
+                    else if (implicit)
+                        st = ST_START;
+                    else
+                        enter(ST_DIST);
+                }
+            }
+            st = r.rc ? (u32)ST_END : st;
+        }
+
+        /* ---- (B) a literal, twice ---- */
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            const bool on = st == ST_LIT;
+            if (on && ctx) { /* context_id(): yeast.c:698-755 */
+                u32 cid;
+                if (cur_mode == 0)
+                    cid = c.p1 & 0x3f;
+                else if (cur_mode == 1)
+                    cid = c.p1 >> 2;
+                else if (cur_mode == 2)
+                    cid = lut[c.p1] | lut[256 + c.p2];
+                else
+                    cid = ((u32)lut[512 + c.p1] << 3) | lut[512 + c.p2];
+                offL = (u32)wl->lt[cid * S + slot] << 4;
+            }
+            u32 e = lookup(on, offL, rootL);
+            asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1));
+            if (decode(on, e, rootL)) {
+                u32 sym = e >> 4;
+                gst8(c.outp, sym);
+                c.outp++;
+                maxd = maxd < c.wsize ? maxd + 1 : maxd;
+                c.p2 = c.p1;
+                c.p1 = sym;
+                if (--insert == 0) {
+                    if (mlen == 0)
+                        st = ST_END; /* :1227 */
+                    else if (implicit)
+                        st = ST_START;
+                    else
+                        enter(ST_DIST);
+                } else
+                    enter(ST_LIT);
+            }
+            st = r.rc ? (u32)ST_END : st;
+        }
+
+        /* ---- (C) the distance symbol: distance() yeast.c:761-789 ---- */
+        {
+            const bool on = st == ST_DIST;
+            if (on && c.dist_codes > 1)
+                offD = (u32)wl->dt[(copy > 4 ? 3 : copy - 2) * S + slot] << 4;
+            u32 e = lookup(on, offD, rootD);
+            asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1));
+            bool ok = decode(on, e, rootD);
+            if (ok) {
+                u32 ds = e >> 4;
+                if (ds < 16) {
+                    u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
+                    u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
+                    u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
+                    int dl = (int)(k >> 1) + 1;
+                    dl = (k & 1) ? dl : -dl;
+                    dl = ds < 4 ? 0 : dl;
+                    dist = (i32)rv + dl;
+                } else if (ds < 16 + c.direct)
+                    dist = (i32)ds - 15;
+                else { /* at most 2^30 + 121: 32 bits are enough */
+                    u32 dn = ds - c.direct - 16;
+                    u32 dx = 1 + (dn >> (c.postfix + 1));
+                    dx = dx > 25 ? 25 : dx; /* only after a read failure */
+                    u32 x1 = bits_mid(dx, ok);
+                    u32 o2 = ((2 + ((dn >> c.postfix) & 1)) << dx) - 4;
+                    dist = (i32)(((o2 + x1) << c.postfix) + (dn & ((1u << c.postfix) - 1)) + c.direct + 1);
+                }
+                if (ok) {
+                    if (ds && dist > 0 && dist <= (i32)maxd) {
+                        c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
+                    }
+                    st = ST_START;
+                }
+            }
+            st = r.rc ? (u32)ST_END : st;
+        }
+
+        /* ---- (D) a copy begins: where its bytes come from ---- */
+        if (st == ST_START) {
             if (dist <= 0) {
                 rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
-            } else if (dist > (i64)maxd) { /* static dictionary: dict_word() yeast.c:908-949 */
-                u64 id = (u64)dist - maxd - 1;
+            } else if ((u32)dist > maxd) { /* static dictionary: dict_word() yeast.c:908-949 */
+                u32 id = (u32)dist - maxd - 1;
                 u32 de = c.sh->dict[copy < 32 ? copy : 0];
                 u32 nd = de >> 24;
-                u64 xform = id >> nd;
+                u32 xform = id >> nd;
                 if (copy > 24 || copy < 4 || xform >= 121) {
                     rd_fail(r, YS_INVALID); /* :921-924, :929-930 */
                 } else {
-                    u32 hdr = c.sh->xf[(u32)xform];
+                    u32 hdr = c.sh->xf[xform];
                     u32 op = hdr & 255, omit = (hdr >> 8) & 255;
                     u32 wlen = op == 3 || op == 4 ? (copy > omit ? copy - omit : 0) : copy;
                     u32 total = ((hdr >> 16) & 255) + wlen + (hdr >> 24);
                     if (total > mlen) {
                         rd_fail(r, YS_INVALID); /* :1269 */
                     } else {
-                        u32 index = (u32)id & ((1u << nd) - 1);
-                        csrc = c.xdict + c.sh->xbase[(u32)xform * YS_XD_LENS + copy - 4] + index * total;
+                        u32 index = id & ((1u << nd) - 1);
+                        csrc = c.xdict + c.sh->xbase[xform * YS_XD_LENS + copy - 4] + index * total;
                         crem = total;
                         cD = 0x40000000u;
                         mlen -= total;
@@ -392,35 +421,25 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                 cD = (u32)dist;
                 mlen -= copy;
             }
-            st = ST_COPY;
-        }
-        /* ---- set up the next piece of the copy in progress (fetched on the next trip) ---- */
-        if (st == ST_COPY && !r.rc) {
-            u32 m = crem < 32 ? crem : 32;
-            psrc = csrc;
-            if (c.outp + 40 > out_end && cD < 0x40000000u) {
-                /* the last bytes of the output region: short pieces, fetched byte by byte */
-                m = m < cD ? m : cD;
-                m = m < 8 ? m : 8;
-                pmode = 0;
-                psafe = 1;
-                csrc += m;
-            } else if (cD < 8) {
-                pmode = cD;
-                psafe = 0;
-                /* what is left continues one whole number of periods back */
-                u32 back = (0x1c1e1e201e2020ull >> (8 * (cD - 1))) & 255; /* largest multiple of the period <= 32 */
-                csrc = c.outp + 32 - back;
-                cD = back;
-            } else {
-                pmode = 0;
-                psafe = 0;
-                m = m < cD ? m : cD;
-                if (m == cD)
-                    cD *= 2; /* a whole period is written: twice as far back is the same data */
+            st = r.rc ? (u32)ST_END : (u32)ST_COPY;
+            if (st == ST_COPY && crem == 0) { /* a transform that leaves nothing of its word */
+                if (mlen)
+                    enter(ST_CMD);
                 else
-                    csrc += m;
+                    st = ST_END;
             }
+        }
+        /* ---- and the next piece of the copy in progress (fetched on the next pass) ---- */
+        if (st == ST_COPY) {
+            u32 m = crem < 32 ? crem : 32;
+            m = m < cD ? m : cD;
+            psrc = csrc;
+            psafe = c.outp + 40 > out_end;
+            m = psafe && m > 8 ? 8 : m;
+            if (m == cD)
+                cD *= 2; /* a whole period is written: twice as far back is the same data */
+            else
+                csrc += m;
             pdst = c.outp;
             pn = m;
             c.outp += m;
@@ -434,42 +453,23 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                     st = ST_END;
             }
         }
-        st = r.rc ? (u32)ST_END : st;
-
-        /* ---- tables of the next lookup that depend on what was just decoded ---- */
-        if (st == ST_LIT && ctx) { /* context_id(): yeast.c:698-755 */
-            u32 cid;
-            if (cur_mode == 0)
-                cid = c.p1 & 0x3f;
-            else if (cur_mode == 1)
-                cid = c.p1 >> 2;
-            else if (cur_mode == 2)
-                cid = lut[c.p1] | lut[256 + c.p2];
-            else
-                cid = ((u32)lut[512 + c.p1] << 3) | lut[512 + c.p2];
-            offL = (u32)wl->lt[cid * S + slot] << 4;
-        } else if (st == ST_DIST && c.dist_codes > 1)
-            offD = (u32)wl->dt[(copy > 4 ? 3 : copy - 2) * S + slot] << 4;
     }
     /* meta-block end (or failure): the piece set up last was valid */
     if (pn) {
-        u64 pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0;
-        if (psafe) {
-            for (u32 b = 0; b < pn; b++)
-                pd0 |= (u64)gld8(psrc + b) << (8 * b);
-        } else {
-            pd0 = gld64u(psrc);
-            if (pn > 8 && !pmode)
-                pd1 = gld64u(psrc + 8);
-            if (pn > 16 && !pmode)
-                pd2 = gld64u(psrc + 16);
-            if (pn > 24 && !pmode)
-                pd3 = gld64u(psrc + 24);
+        for (u32 b = 0; b < pn; b += 8) {
+            u32 k = pn - b < 8 ? pn - b : 8;
+            u64 v = 0;
+            if (psafe || k < 8) {
+                for (u32 j = 0; j < k; j++)
+                    v |= (u64)gld8(psrc + b + j) << (8 * j);
+                for (u32 j = 0; j < k; j++)
+                    gst8(pdst + b + j, (u32)(v >> (8 * j)) & 255);
+            } else
+                gst64u(pdst + b, gld64u(psrc + b));
         }
-        store_pending(pd0, pd1, pd2, pd3);
     }
     group_sync_mem();
-    if (!ctx) { /* context for the next meta-block */
+    { /* literal context for the next meta-block */
         u64 got = got_of(c);
         c.p1 = got >= 1 ? gld8(c.outp - 1) : 0;
         c.p2 = got >= 2 ? gld8(c.outp - 2) : 0;
