@@ -317,8 +317,8 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     const bool flat = lanes <= 4;
     /* one stream per lane, half-filled wavefronts: two wavefronts per SIMD instead of one */
     const int half = lanes == 1 && env_int("YEAST_HALF", 1);
-    unsigned per_block = 256u / (unsigned)lanes / (half ? 2u : 1u);
-    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half ? 2 : 1) : 4);
+    unsigned per_block = 256u / (unsigned)lanes / (half == 2 ? 4u : half ? 2u : 1u);
+    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : half ? 2 : 1) : 4);
     size_t want_blocks = (n + per_block - 1) / per_block;
     size_t max_blocks = (size_t)d.cus * blocks_per_cu;
     unsigned blocks = (unsigned)(want_blocks < max_blocks ? want_blocks : max_blocks);

@@ -199,8 +199,21 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
     /* nothing loaded above is still on its way when the loop starts (a wait placed inside the loop
        for the first pass's sake would be paid on every pass) */
     asm volatile("" : "+v"(offI), "+v"(offL), "+v"(offD), "+v"(cur_mode), "+v"(q0));
+#ifdef YS_PROFILE
+    u64 pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pmark = __builtin_readcyclecounter();
+    u32 npass = 0;
+#define LMARK(i) do { u64 now_ = __builtin_readcyclecounter(); pt[i] += now_ - pmark; pmark = now_; } while (0)
+#define LWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define LMARK(i) do { } while (0)
+#define LWAIT() do { } while (0)
+#endif
     enter(ST_CMD);
     while (st != ST_END) {
+#ifdef YS_PROFILE
+        npass++;
+#endif
+        LMARK(11);
         /* ---- block switch (rare): type code, count code, the new type's tables ---- */
         if (!SIMPLE && st == ST_BSW) {
             u32 sh = 8 * cat;
@@ -240,6 +253,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             asm volatile("" : "+v"(offI), "+v"(cur_mode), "+v"(q0), "+v"(q1));
         }
 
+        LMARK(0);
         /* ---- (A) the piece set up on the last pass, and the insert-and-copy symbol ---- */
         {
             u64 pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0;
@@ -262,7 +276,10 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             }
             const bool on = st == ST_CMD;
             u32 e = lookup(on, offI, rootI);
+            LMARK(1);
+            LWAIT();
             asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1), "+v"(pd0), "+v"(pd1), "+v"(pd2), "+v"(pd3), "+v"(pe));
+            LMARK(2);
             if (pn) {
                 if (psafe) { /* the last bytes of the output region: exact */
                     for (u32 b = 0; b < pn; b++)
@@ -311,6 +328,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             st = r.rc ? (u32)ST_END : st;
         }
 
+        LMARK(3);
         /* ---- (B) a literal, twice ---- */
 #pragma unroll
         for (int rep = 0; rep < 2; rep++) {
@@ -328,7 +346,10 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                 offL = (u32)wl->lt[cid * S + slot] << 4;
             }
             u32 e = lookup(on, offL, rootL);
+            LMARK(4);
+            LWAIT();
             asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1));
+            LMARK(5);
             if (decode(on, e, rootL)) {
                 u32 sym = e >> 4;
                 gst8(c.outp, sym);
@@ -349,13 +370,17 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             st = r.rc ? (u32)ST_END : st;
         }
 
+        LMARK(6);
         /* ---- (C) the distance symbol: distance() yeast.c:761-789 ---- */
         {
             const bool on = st == ST_DIST;
             if (on && c.dist_codes > 1)
                 offD = (u32)wl->dt[(copy > 4 ? 3 : copy - 2) * S + slot] << 4;
             u32 e = lookup(on, offD, rootD);
+            LMARK(7);
+            LWAIT();
             asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1));
+            LMARK(8);
             bool ok = decode(on, e, rootD);
             if (ok) {
                 u32 ds = e >> 4;
@@ -387,14 +412,15 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             st = r.rc ? (u32)ST_END : st;
         }
 
+        LMARK(9);
         /* ---- (D) a copy begins: where its bytes come from ---- */
         if (st == ST_START) {
             if (dist <= 0) {
                 rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
             } else if ((u32)dist > maxd) { /* static dictionary: dict_word() yeast.c:908-949 */
                 u32 id = (u32)dist - maxd - 1;
-                u32 de = c.sh->dict[copy < 32 ? copy : 0];
-                u32 nd = de >> 24;
+                u32 ci = copy - 4; /* NDBITS[copy] (yeast.c:916-919), four bits per word length */
+                u32 nd = ci < 16 ? (u32)(0x7877899aaaaabbaaull >> (4 * (ci & 15))) & 15 : (0x55667u >> (4 * (ci & 7))) & 15;
                 u32 xform = id >> nd;
                 if (copy > 24 || copy < 4 || xform >= 121) {
                     rd_fail(r, YS_INVALID); /* :921-924, :929-930 */
@@ -453,7 +479,16 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                     st = ST_END;
             }
         }
+        LMARK(10);
     }
+#ifdef YS_PROFILE
+    if ((threadIdx.x & 63) == 0 && c.cap >= 128) { /* the profile build's output bytes are not meant to be looked at */
+        u64 *prof = (u64 *)(c.out + c.cap - 128);
+        for (int i = 0; i < 12; i++)
+            prof[i] = pt[i];
+        prof[12] = npass;
+    }
+#endif
     /* meta-block end (or failure): the piece set up last was valid */
     if (pn) {
         for (u32 b = 0; b < pn; b += 8) {
