@@ -190,7 +190,7 @@ def main():
     value = out_bytes * world / (dt / args.steps) / 1e9
     achieved = algo / (k_ms * 1e-3) / 1e9
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/prof_summary.py from the PMC passes
     if os.path.exists(tf):
         try:
             t = json.load(open(tf))
@@ -211,7 +211,7 @@ def main():
                    "streams_per_gpu": n, "order": args.order, "out_bytes_per_gpu": out_bytes, "in_bytes_per_gpu": in_bytes,
                    "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "1")),
                    "parallelism": "%d independent shards" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_decode_lean<32>" if n >= 16384 and not args.lanes else "k_decode*", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo, "kernel_ms": k_ms, "check_kernel_ms": c_ms},
     }

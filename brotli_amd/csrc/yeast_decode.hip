@@ -51,39 +51,6 @@ __global__ __launch_bounds__(256, YS_MIN_WAVES) void k_decode(ys_params p)
     }
 }
 
-/* Batch kernel: every group of a wavefront starts its stream at the same time, so header
-   parsing, the flat command loop and the record write-out run converged across the S streams
-   of the wavefront; a wavefront takes the next S streams when all of its groups are done.
-   S * G = 64 fills the wavefront; S * G = 32 leaves the upper half idle so that two wavefronts
-   fit each SIMD and one's instruction and memory latency hides behind the other's work. */
-template <int G, int S>
-__global__ __launch_bounds__(256, 64 / (S * G)) void k_decode_flat(ys_params p)
-{
-    __shared__ Shared sh;
-    __shared__ WaveLds<S> wlds[4];
-    shared_fill(sh, p.xforms);
-    u32 lane = threadIdx.x;
-    u32 sub = lane & (G - 1);
-    u32 wave = (blockIdx.x * blockDim.x + lane) >> 6;
-    u32 slot = (lane & 63) / G;
-    u8 *ws = p.ws + (u64)(wave * S + (slot < S ? slot : 0)) * p.ws_stride;
-    const u32 limit = p.retry ? *p.retry_count : p.n;
-    for (;;) {
-        u32 base = 0;
-        if ((lane & 63) == 0)
-            base = atomicAdd(p.counter, (u32)S);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= limit)
-            break;
-        u32 job = base + slot;
-        if (slot < S && job < limit) {
-            if (p.retry)
-                job = p.retry_list[job];
-            decode_stream<G, false, S>(p, job, ws, &sh, sub, &wlds[lane >> 6]);
-        }
-    }
-}
-
 /* ---------------------------------------------------------------- launchers */
 
 extern "C" int ys_upload_constants(const u8 *lut768) { return ys_upload_constants_impl(lut768); }
@@ -107,27 +74,6 @@ extern "C" int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cm
     case 64: return launch_decode_t<64, false>(*p, groups, st);
     case 16: return launch_decode_t<16, false>(*p, groups, st);
     case 8: return launch_decode_t<8, false>(*p, groups, st);
-    }
-    return -1;
-}
-
-template <int G, int S>
-static int launch_flat_t(const ys_params &p, u32 groups, hipStream_t st)
-{
-    u32 per_block = 4 * S;
-    u32 blocks = (groups + per_block - 1) / per_block;
-    hipLaunchKernelGGL((k_decode_flat<G, S>), dim3(blocks), dim3(256), 0, st, p);
-    return (int)hipGetLastError();
-}
-
-/* the batch (flat) kernel: lanes_per_stream 1, 2 or 4; half != 0: half-filled wavefronts, two per SIMD */
-extern "C" int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, int half, unsigned groups, void *stream)
-{
-    hipStream_t st = (hipStream_t)stream;
-    switch (lanes_per_stream) {
-    case 1: return half ? launch_flat_t<1, 32>(*p, groups, st) : launch_flat_t<1, 64>(*p, groups, st);
-    case 2: return launch_flat_t<2, 32>(*p, groups, st);
-    case 4: return launch_flat_t<4, 16>(*p, groups, st);
     }
     return -1;
 }

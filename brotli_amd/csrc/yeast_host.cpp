@@ -25,7 +25,6 @@ extern const unsigned char ys_transforms[2420];
 int ys_upload_constants(const u8 *lut768);
 int ys_upload_check_constants(const u32 *x2n);
 int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned groups, void *stream);
-int ys_launch_decode_flat(const ys_params *p, int lanes_per_stream, int half, unsigned groups, void *stream);
 int ysl_upload_constants(const u8 *lut768);
 int ysl_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base, u8 *xdict, void *stream);
 int ysl_launch(const ys_params *p, int half, unsigned streams, void *stream);
@@ -258,8 +257,8 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         lanes = env_int("YEAST_LANES", n >= 16384 ? 1 : YS_LANES_WAVE);
     if (cmp)
         lanes = 64;
-    if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 64 && lanes != YS_LANES_WAVE) {
-        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: lanes_per_stream must be 1, 2, 4, 8, 16, 64 or 65");
+    if (lanes != 1 && lanes != 8 && lanes != 16 && lanes != 64 && lanes != YS_LANES_WAVE) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: lanes_per_stream must be 1, 8, 16, 64 or 65");
         return -1;
     }
     /* counters: [0] main queue head, [1] retry queue head, [2] retry count; then the retry list */
@@ -312,11 +311,12 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         if (e)
             return fail("decode launch", (hipError_t)e);
     } else {
-    /* 1, 2, 4 lanes: the batch kernel (streams of a wavefront in lock step, flat command loop);
-       8, 16, 64 lanes: the cooperative kernel (wide copies, lowest latency per stream) */
-    const bool flat = lanes <= 4;
-    /* one stream per lane, half-filled wavefronts: two wavefronts per SIMD instead of one */
-    const int half = lanes == 1 && env_int("YEAST_HALF", 1);
+    /* 1 lane: the batch kernel (one stream per lane, yeast_lane.hip);
+       8, 16, 64 lanes: the cooperative kernel (wide copies; compare mode) */
+    const bool flat = lanes == 1;
+    /* one stream per lane: half-filled wavefronts (two per SIMD, the default), full ones (0) or
+       quarter-filled ones (2) */
+    const int half = flat ? env_int("YEAST_HALF", 1) : 0;
     unsigned per_block = 256u / (unsigned)lanes / (half == 2 ? 4u : half ? 2u : 1u);
     unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : half ? 2 : 1) : 4);
     size_t want_blocks = (n + per_block - 1) / per_block;
@@ -332,19 +332,16 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         return -1;
     p.ws = (u8 *)d.ws.p;
     p.ws_stride = stride;
-    if (env_int("YEAST_EXP_SHARED_WS", 0))
-        p.ws_stride = 0; /* experiment (identical streams only): every stream uses the same table memory */
-    if (lanes == 1 && !env_int("YEAST_FLAT_OLD", 0)) {
-        /* the lean loop (yeast_lean.h); narrow root tables keep the tables of all resident streams
-           in the Infinity Cache */
-        unsigned rl = (unsigned)env_int("YEAST_LEAN_ROOT_LIT", 6), ri = (unsigned)env_int("YEAST_LEAN_ROOT_IAC", 8),
-                 rd = (unsigned)env_int("YEAST_LEAN_ROOT_DIST", 6);
+    if (flat) {
+        /* root table widths of the batch kernel's tables */
+        unsigned rl = (unsigned)env_int("YEAST_LEAN_ROOT_LIT", 7), ri = (unsigned)env_int("YEAST_LEAN_ROOT_IAC", 8),
+                 rd = (unsigned)env_int("YEAST_LEAN_ROOT_DIST", 7);
         auto clamp = [](unsigned v) { return v < 4 ? 4u : v > 8 ? 8u : v; };
         p.rootcaps = 8u | (clamp(rl) << 8) | (clamp(ri) << 16) | (clamp(rd) << 24);
         e = ysl_launch(&p, half, groups, st);
     }
     else
-        e = flat ? ys_launch_decode_flat(&p, lanes, half, groups, st) : ys_launch_decode(&p, lanes, cmp, groups, st);
+        e = ys_launch_decode(&p, lanes, cmp, groups, st);
     if (e)
         return fail("decode launch", (hipError_t)e);
     }

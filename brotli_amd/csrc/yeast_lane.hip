@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, 64 / S) void k_decode_lean(ys_params p)
         if (slot < S && job < limit) {
             if (p.retry)
                 job = p.retry_list[job];
-            decode_stream<1, false, 1000 + S>(p, job, ws, &sh, 0, &wlds[lane >> 6]);
+            decode_stream<1, false, S>(p, job, ws, &sh, 0, &wlds[lane >> 6]);
         }
     }
 }

@@ -49,74 +49,6 @@ DEV void shared_fill(Shared &sh, const u8 *xforms, const u32 *xbase = nullptr)
 
 /* ------------------------------------------------------------------ state */
 
-/* per-wavefront LDS of the batch kernel: the copy queues, the literal table map and the output
-   staging rings.  Every array is [index][stream] so that the 64 streams of a wavefront touch 64
-   different banks whatever their indices are. */
-#define FQ 8
-#ifndef YS_HOLD
-#define YS_HOLD 12 /* trips a literal may wait for its context bytes before a drain is forced */
-#endif
-#define RB 256        /* bytes of output staged per stream (the newest RB bytes of its output) */
-#define RU (RB / 8)   /* the ring is kept in 8-byte units */
-#define RB_SLACK 48   /* a drain is forced when fewer bytes than this are free */
-template <int S> /* S streams share the wavefront */
-struct WaveLds {
-    u32 qa[FQ * S]; /* destination, bytes from the start of the meta-block's output */
-    u32 qb[FQ * S]; /* bytes to produce | kind << 28 */
-    u32 qc[FQ * S]; /* copy: distance; dictionary: transform << 25 | word bytes << 20 | word offset */
-    u16 lt[64 * S]; /* [context][stream]: byte offset of the literal table >> 4 */
-    u64 ring[RU * S]; /* [unit][stream] */
-};
-
-/* byte offset of output address a (low bits) in the ring array of a wavefront with S streams */
-template <int S>
-DEV u32 ring_at(u32 slot, u32 a) { return ((((a >> 3) & (RU - 1)) * S + slot) << 3) | (a & 7); }
-
-/* n (1..8) bytes of v to output address a, staged: a read-modify-write of the one or two units the
-   bytes fall in (bytes of v beyond n are ignored; neighbouring bytes in the units are kept) */
-template <int S>
-DEV void ring_put(LAS u8 *rb, u32 slot, u32 a, u64 v, u32 n)
-{
-    u32 s = (a & 7) * 8;
-    u64 m = n >= 8 ? ~0ull : ~(~0ull << (8 * n));
-    u32 u0 = (a >> 3) & (RU - 1), u1 = (u0 + 1) & (RU - 1);
-    LAS u64 *w0 = (LAS u64 *)(rb + ((u0 * S + slot) << 3));
-    u64 m0 = m << s;
-    *w0 = (*w0 & ~m0) | ((v << s) & m0);
-    u64 m1 = s ? m >> (64 - s) : 0;
-    if (m1) {
-        LAS u64 *w1 = (LAS u64 *)(rb + ((u1 * S + slot) << 3));
-        *w1 = (*w1 & ~m1) | ((v >> (64 - s)) & m1);
-    }
-}
-
-/* the 8 staged bytes from output address a on */
-template <int S>
-DEV u64 ring_get(LAS u8 *rb, u32 slot, u32 a)
-{
-    u32 s = (a & 7) * 8;
-    u32 u0 = (a >> 3) & (RU - 1), u1 = (u0 + 1) & (RU - 1);
-    u64 w0 = *(LAS u64 *)(rb + ((u0 * S + slot) << 3)), w1 = *(LAS u64 *)(rb + ((u1 * S + slot) << 3));
-    return s ? (w0 >> s) | (w1 << (64 - s)) : w0;
-}
-
-/* one complete 64-byte line from the ring to its place in the output region */
-template <int S>
-DEV void ring_flush_line(LAS u8 *rb, u32 slot, u8 *line)
-{
-    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-    u32 u = ((u32)(u64)line >> 3) & (RU - 1);
-    u64 d[8];
-#pragma unroll
-    for (u32 j = 0; j < 8; j++)
-        d[j] = *(LAS u64 *)(rb + (((u + j) * S + slot) << 3));
-#pragma unroll
-    for (u32 j = 0; j < 4; j++) {
-        u64x2 v = {d[2 * j], d[2 * j + 1]};
-        *(GAS u64x2 *)(line + 16 * j) = v;
-    }
-}
-
 struct Blk { /* one block category: yeast.c:112-123 */
     u32 num, type, prev, left;
     u32 t_type, t_count; /* byte offsets of the two block-switch tables from ws */
@@ -141,12 +73,7 @@ struct Ctx {
     const u8 *dict, *xf, *xdict;
     u32 rootcaps; /* root table widths (Hdr.rootcaps) */
     const Shared *sh;
-    void *wl; /* WaveLds<S> of this wavefront (batch kernel only) */
-#ifdef YS_PROFILE
-    u64 t_hdr, t_loop, t_drain, t_look, t_dload;
-    u64 t_s0, t_s2, t_s3, t_s4, t_s5, t_mark;
-    u32 n_trips, n_drains, n_need, n_qfull, n_rfull, n_ents;
-#endif
+    void *wl; /* LeanLds<S> of this wavefront (batch kernel only) */
 };
 
 DEV const u16 *tab_at(const Ctx &c, u32 off) { return (const u16 *)(c.ws + off); }
@@ -253,43 +180,6 @@ DEV void emit_copy(Ctx &c, u32 n, u32 d, u32 sub, bool ctx)
         for (u32 i = (n8 << 3) + sub; i < n; i += G)
             gst8(dst + i, gld8(from + i));
     } else { /* overlapping: byte i repeats byte i mod d of the source */
-        if (ctx) {
-            c.p1 = gld8(from + (n - 1) % d);
-            c.p2 = gld8(from + (n - 2) % d);
-        }
-        u32 m = sub % d, step = G % d;
-        for (u32 i = sub; i < n; i += G) {
-            gst8(dst + i, gld8(from + m));
-            m += step;
-            if (m >= d)
-                m -= d;
-        }
-    }
-    c.outp += n;
-}
-
-/* The same copy for the flat loop when there is slack behind the destination:
-   whole 8-byte units only; up to 7 bytes beyond the end are scribbled on and
-   overwritten by whatever is decoded next (never read before that). */
-template <int G>
-DEV void emit_copy_wild(Ctx &c, u32 n, u32 d, u32 sub, bool ctx)
-{
-    u8 *dst = c.outp;
-    const u8 *from = dst - d;
-    if (d >= n || (G == 1 && d >= 8)) {
-        if (ctx) {
-            if (d >= n) {
-                u32 v = gld8(from + n - 2) | (gld8(from + n - 1) << 8);
-                c.p2 = v & 255;
-                c.p1 = v >> 8;
-            } else {
-                c.p1 = gld8(from + (n - 1) % d);
-                c.p2 = gld8(from + (n - 2) % d);
-            }
-        }
-        for (u32 j = sub * 8; j < n; j += G * 8)
-            gst64u(dst + j, gld64u(from + j));
-    } else {
         if (ctx) {
             c.p1 = gld8(from + (n - 1) % d);
             c.p2 = gld8(from + (n - 2) % d);
@@ -597,13 +487,8 @@ DEV void emit_raw(Ctx &c, const u8 *from, u32 n, u32 sub)
 DEV void group_sync_mem() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 /* ------------------------------------------------ batch kernel command loop */
-#ifdef YS_PROFILE
-#define YS_MARK(field) do { u64 now_ = __builtin_readcyclecounter(); c.field += now_ - c.t_mark; c.t_mark = now_; } while (0)
-#else
-#define YS_MARK(field) do { } while (0)
-#endif
 
-
+/* what the meta-block header hands to the command loop of the batch kernel (yeast_lean.h) */
 struct FlatEnv {
     const u32 *itab, *dtab, *lit_tab;
     const u8 *mode;
@@ -611,564 +496,12 @@ struct FlatEnv {
     bool ctx;
 };
 
-/* spread the low 8 bits of b to the low bit of 8 bytes */
-DEV u64 spread8(u32 b)
-{
-    u64 x = b & 255;
-    x = (x | (x << 28)) & 0x0000000f0000000full;
-    x = (x | (x << 14)) & 0x0003000300030003ull;
-    x = (x | (x << 7)) & 0x0101010101010101ull;
-    return x;
-}
-
-/* The command loop of yeast.c:1166-1295 as a flat state machine.  Every trip performs exactly
- * one table lookup per stream (an insert-and-copy, literal or distance symbol, or the second
- * level of a long code), so the streams that share a wavefront stay converged on the expensive
- * part whatever mix of commands they are in.  The body is written as straight-line code with
- * selects: in a wavefront of 64 streams every kind of trip occurs on every pass anyway, so
- * branching around them would only add mask bookkeeping.  Window copies and dictionary words are
- * validated and accounted for where they are decoded, but their bytes are moved later: they go to
- * a short per-stream queue in LDS and the whole wavefront drains its queues together (the "second
- * pass" that resolves LZ77 and dictionary references).
- * SIMPLE: no block switching, one distance code (checked for the whole wavefront). */
-template <int G, int S, bool SIMPLE>
-DEV void run_flat(Ctx &c, u32 &mlen, u32 sub, const FlatEnv &fe)
-{
-    enum { ST_CMD = 0, ST_LIT = 1, ST_DIST = 2, ST_END = 3, ACT_NONE = 4, ST_COPY = 5 };
-    enum { K_FAR = 0, K_BYTES = 1, K_SLOW = 2, K_DICT = 3 };
-    Rd &r = c.r;
-    WaveLds<S> *wl = (WaveLds<S> *)c.wl;
-    const u32 slot = (threadIdx.x & 63) / G;
-    LAS u8 *const rb = (LAS u8 *)wl->ring;
-    const bool ctx = fe.ctx;
-    const u64 *cmd_tab = c.sh->cmd;
-    u32 cur_mode = fe.cur_mode;
-    u32 st = ST_CMD;
-    u32 offI = gld32(fe.itab), offL = fe.offL0, offD = fe.offD0;
-    u32 off = offI;
-    u32 insert = 0, copy = 0, implicit = 0;
-    u32 link = 0;             /* root entry of a long code whose second lookup is this trip's work */
-    /* last two bytes of the newest copy: raw load results still in flight (nothing is computed
-       from them until the next lookup has returned), 1 = two bytes, 2 = one byte + pn_c */
-    u32 pn = 0, pn_c = 0, pn_valid = 0;
-    u8 *const mb_base = c.outp; /* queue entries hold offsets from here (mlen < 2^25) */
-    /* Output is staged: bytes below fl are in the output region (final), bytes from fl up to
-       outp live in the ring -- literals at once, queued copies when the queue is drained.
-       outp - fl never exceeds RB. */
-    u8 *fl = c.outp;
-    u32 qn = 0, pend_rel = 0, stale = 0, held = 0;
-    /* max distance into the window = min(bytes produced so far, window size), kept incrementally */
-    u64 got0 = got_of(c);
-    u32 maxd = got0 > c.wsize ? c.wsize : (u32)got0;
-    const bool lds_lt = SIMPLE ? ctx : (ctx && c.L.num == 1);
-    if (lds_lt) { /* the 64 table offsets of the only literal block type move to LDS */
-        for (u32 n = sub; n < 64; n += G)
-            wl->lt[n * S + slot] = (u16)(gld32(fe.lit_tab + n) >> 4);
-    }
-    u32 nxt_empty = 0;
-    /* a refill in the middle of a trip: the prefetched word is in a register (pinned after the
-       lookup); no new load is started here, so the top of the next trip never waits */
-    auto refill_mid = [&]() {
-        if (r.have <= 32) {
-            if (nxt_empty) {
-                r.nxt = gld32(r.p + r.idx);
-                asm volatile("" : "+v"(r.nxt));
-            }
-            r.w |= (u64)r.nxt << r.have;
-            u32 add = r.rem < 32 ? r.rem : 32;
-            r.have += add;
-            r.rem -= add;
-            r.idx += add ? 1 : 0;
-            nxt_empty = 1;
-        }
-    };
-    auto next_lit_table = [&]() -> u32 {
-        u32 id = (c.L.type << 6) + context_id(c, c.p1, c.p2, cur_mode);
-        if (SIMPLE)
-            return (u32)wl->lt[id * S + slot] << 4;
-        return lds_lt ? (u32)wl->lt[id * S + slot] << 4 : gld32(fe.lit_tab + id);
-    };
-    auto staged = [&](const u8 *q) -> u32 { return rb[ring_at<S>(slot, (u32)(u64)q)]; };
-    /* ring -> output region: whole 64-byte lines below lim; exact: every byte below lim */
-    auto flush = [&](u8 *lim, bool exact) {
-        u8 *lim64 = exact ? lim : (u8 *)((u64)lim & ~63ull);
-        while (fl < lim64 && ((u64)fl & 63)) { /* ragged start: stream start, after a slow copy */
-            if (G == 1 || sub == 0)
-                gst8(fl, staged(fl));
-            fl++;
-        }
-        while (fl + 64 <= lim64) {
-            if (G == 1 || sub == 0)
-                ring_flush_line<S>(rb, slot, fl);
-            fl += 64;
-        }
-        if (exact)
-            while (fl < lim) {
-                if (G == 1 || sub == 0)
-                    gst8(fl, staged(fl));
-                fl++;
-            }
-    };
-    /* the last two bytes of the output so far, when nothing is queued */
-    auto last_two = [&]() {
-        group_sync_mem(); /* bytes below fl are read back from the output region */
-        u64 got = got_of(c);
-        u32 b1 = 0, b2 = 0;
-        if (got >= 1)
-            b1 = c.outp - 1 >= fl ? staged(c.outp - 1) : gld8(c.outp - 1);
-        if (got >= 2)
-            b2 = c.outp - 2 >= fl ? staged(c.outp - 2) : gld8(c.outp - 2);
-        c.p1 = b1;
-        c.p2 = b2;
-    };
-    /* second pass over one stream's queue, entries in order, four source fetches per round trip */
-    constexpr u32 DB = 4;
-    auto drain = [&]() {
-        for (u32 k0 = 0; k0 < qn; k0 += DB) {
-            u32 ea[DB], eb[DB], ec[DB];
-            u64 d0[DB], d1[DB], d2[DB];
-#ifdef YS_PROFILE
-            u64 tb0 = __builtin_readcyclecounter();
-#endif
-#pragma unroll
-            for (u32 j = 0; j < DB; j++) {
-                u32 k = k0 + j;
-                ea[j] = eb[j] = ec[j] = 0;
-                d0[j] = d1[j] = d2[j] = 0;
-                if (k < qn) {
-                    ea[j] = wl->qa[k * S + slot];
-                    eb[j] = wl->qb[k * S + slot];
-                    ec[j] = wl->qc[k * S + slot];
-                    u32 kind = eb[j] >> 28, len = 0;
-                    const u8 *src = c.dict;
-                    if (kind == K_FAR) {
-                        src = mb_base + ea[j] - ec[j];
-                        len = eb[j] & 0xfffffffu;
-                    } else if (kind == K_DICT) {
-                        src = c.dict + (ec[j] & 0xfffffu);
-                        len = (ec[j] >> 20) & 31;
-                    }
-                    if (len)
-                        d0[j] = gld64u(src);
-                    if (len > 8)
-                        d1[j] = gld64u(src + 8);
-                    if (len > 16)
-                        d2[j] = gld64u(src + 16);
-                }
-            }
-#ifdef YS_PROFILE
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            c.t_dload += __builtin_readcyclecounter() - tb0;
-#endif
-#pragma unroll
-            for (u32 j = 0; j < DB; j++) {
-                u32 k = k0 + j;
-                if (k < qn) {
-                    u32 kind = eb[j] >> 28, n = eb[j] & 0xfffffffu;
-                    u8 *dst = mb_base + ea[j];
-                    u32 a = (u32)(u64)dst;
-                    if (kind == K_FAR || kind == K_DICT) {
-                        u32 plen = 0, slen = 0, len = n;
-                        u64 pre = 0, suf = 0, w0 = d0[j], w1 = d1[j], w2 = d2[j];
-                        if (kind == K_DICT) {
-                            u32 xform = ec[j] >> 25;
-                            u32 hdr = c.sh->xf[xform], op = hdr & 255;
-                            plen = (hdr >> 16) & 255;
-                            slen = hdr >> 24;
-                            len = (ec[j] >> 20) & 31;
-                            pre = c.sh->xpre[xform];
-                            suf = c.sh->xsuf[xform];
-                            if (op == 1 || op == 2) { /* UPPER(): yeast.c:809-827, on the fetched word */
-                                u32 x32 = 0, x5 = 0, i = 0;
-#ifdef YS_PROFILE
-                                c.n_rfull++;
-#endif
-                                do {
-                                    u64 w = i < 8 ? w0 : i < 16 ? w1 : w2;
-                                    u32 ch = (u32)(w >> (8 * (i & 7))) & 255;
-                                    if (ch < 192) {
-                                        if (ch >= 97 && ch <= 122)
-                                            x32 |= 1u << i;
-                                        i += 1;
-                                    } else if (ch < 224) {
-                                        if (i + 1 < len)
-                                            x32 |= 1u << (i + 1);
-                                        i += 2;
-                                    } else {
-                                        if (i + 2 < len)
-                                            x5 |= 1u << (i + 2);
-                                        i += 3;
-                                    }
-                                } while (op == 2 && i < len);
-                                w0 ^= (spread8(x32) << 5) | (spread8(x5) * 5);
-                                w1 ^= (spread8(x32 >> 8) << 5) | (spread8(x5 >> 8) * 5);
-                                w2 ^= (spread8(x32 >> 16) << 5) | (spread8(x5 >> 16) * 5);
-                            }
-                        }
-                        if (plen)
-                            ring_put<S>(rb, slot, a, pre, plen);
-                        a += plen;
-                        if (len)
-                            ring_put<S>(rb, slot, a, w0, len);
-                        if (len > 8)
-                            ring_put<S>(rb, slot, a + 8, w1, len - 8);
-                        if (len > 16)
-                            ring_put<S>(rb, slot, a + 16, w2, len - 16);
-                        if (len > 24) { /* a long copy that fits the ring (never a dictionary word) */
-                            const u8 *src = dst - ec[j];
-                            for (u32 i = 24; i < len; i += 8)
-                                ring_put<S>(rb, slot, a + i, gld64u(src + i), len - i);
-                        }
-                        if (slen)
-                            ring_put<S>(rb, slot, a + len, suf, slen);
-                    } else if (kind == K_BYTES) {
-                        /* near or overlapping copy (byte-serial in yeast.c:1285-1293): 8 bytes at a
-                           time, each group from wherever its source is now.  A distance below 8 is
-                           a repeating pattern: its first 8 bytes are built in a register, and from
-                           there on the same bytes are found a multiple of the distance back. */
-                        u32 d = ec[j], i = 0;
-                        if (d < 8) {
-                            const u8 *src = dst - d;
-                            u64 pat = 0;
-                            if (src >= fl)
-                                pat = ring_get<S>(rb, slot, (u32)(u64)src) & ~(~0ull << (8 * d));
-                            else
-                                for (u32 b = 0; b < d; b++)
-                                    pat |= (u64)(src + b < fl ? gld8(src + b) : staged(src + b)) << (8 * b);
-                            for (u32 w = d; w < 8; w <<= 1)
-                                pat |= pat << (8 * w);
-                            ring_put<S>(rb, slot, a, pat, n);
-                            d *= d >= 4 ? 2 : d == 3 ? 3 : d == 2 ? 4 : 8;
-                            i = 8;
-                        }
-                        for (; i < n; i += 8) {
-                            const u8 *src = dst + i - d;
-                            u64 v;
-                            if (src >= fl)
-                                v = ring_get<S>(rb, slot, (u32)(u64)src);
-                            else if (src + 8 <= fl)
-                                v = gld64u(src);
-                            else {
-                                v = 0;
-                                for (u32 b = 0; b < 8; b++)
-                                    v |= (u64)(src + b < fl ? gld8(src + b) : staged(src + b)) << (8 * b);
-                            }
-                            ring_put<S>(rb, slot, a + i, v, n - i);
-                        }
-                    } else {
-                        /* too long for the ring: bring the output region up to date and copy there;
-                           this is always the newest entry and the drain follows it at once */
-                        flush(dst, true);
-                        group_sync_mem();
-                        copy_exact<G>(dst, n, ec[j], sub);
-                        group_sync_mem();
-                        fl = dst + n;
-                    }
-                }
-            }
-        }
-        qn = 0;
-        flush(c.outp, false);
-    };
-    /* The distance and copy code is the longest part of a trip and only about a third of the
-       streams are at a distance symbol on any one trip, so it runs on odd trips only: a stream
-       that reaches a distance on an even trip sits that trip out, and the code runs half as
-       often with about twice as many streams ready for it. */
-    u32 odd = 1;
-#ifdef YS_PROFILE
-    c.t_mark = __builtin_readcyclecounter();
-#endif
-    while (st != ST_END) {
-        odd ^= 1;
-        /* sits out: a literal whose context bytes are still queued (it waits for the next
-           drain), a distance or an implicit-distance copy on an even trip */
-        const bool hold = (st == ST_LIT && ctx && stale) || ((st == ST_DIST || st == ST_COPY) && !odd);
-        if (!SIMPLE) {
-            if (!link && !hold) {
-                if (st == ST_CMD) {
-                    if (c.I.num > 1) {
-                        if (c.I.left == 0) {
-                            switch_block(c, c.I);
-                            offI = gld32(fe.itab + c.I.type);
-                        }
-                        c.I.left--;
-                    }
-                } else if (st == ST_LIT) {
-                    if (c.L.num > 1) {
-                        if (c.L.left == 0) {
-                            switch_block(c, c.L);
-                            cur_mode = gld8(fe.mode + c.L.type);
-                            if (ctx)
-                                offL = next_lit_table();
-                        }
-                        c.L.left--;
-                    }
-                } else if (st == ST_DIST) {
-                    if (c.D.num > 1) {
-                        if (c.D.left == 0)
-                            switch_block(c, c.D);
-                        c.D.left--;
-                    }
-                    offD = fe.offD0;
-                    if (c.dist_codes > 1)
-                        offD = gld32(fe.dtab + (c.D.type << 2) + (copy > 4 ? 3 : copy - 2));
-                }
-            }
-        }
-        if (!link)
-            off = st == ST_CMD ? offI : st == ST_LIT ? offL : offD;
-
-        /* ---- the one table lookup of this trip ---- */
-        if (nxt_empty) { /* rare: a second refill in the previous trip used up the prefetched word */
-            r.nxt = gld32(r.p + r.idx);
-            asm volatile("" : "+v"(r.nxt));
-            nxt_empty = 0;
-        }
-        rd_refill(r); /* consumes a word that is in a register already; starts the next prefetch */
-        u32 peek = (u32)r.w;
-        u32 idx = link ? (link >> 4) + ((peek >> ROOT) & ((1u << ((link & 15) - ROOT)) - 1)) : (peek & 255);
-        YS_MARK(t_s0);
-        u32 e = gld16((const u16 *)(c.ws + off) + idx);
-#ifdef YS_PROFILE
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(e));
-        YS_MARK(t_look);
-        c.n_trips++;
-#endif
-        /* what this trip does with the entry; ACT_NONE = first half of a long code, or failed */
-        u32 l = e & 15;
-        /* everything issued before the lookup has arrived with it: the prefetched input word
-           (pinned here so that the next refill finds it in a register, not in flight) and the
-           context bytes of the newest copy */
-        asm volatile("" : "+v"(r.nxt));
-        if (pn_valid) {
-            c.p1 = pn_valid == 1 ? pn >> 8 : pn_c;
-            c.p2 = pn & 255;
-            pn_valid = 0;
-        }
-        bool first_half = !link && l > ROOT;
-        const bool nolook = hold || st == ST_COPY; /* nothing is decoded for this stream on this trip */
-        first_half = first_half && !nolook;
-        link = first_half ? e : hold ? link : 0; /* the second half of a long distance code may have to wait */
-        l = first_half || nolook ? 0 : l;
-        u32 act = first_half || hold ? (u32)ACT_NONE : st;
-        if (l > r.have) {
-            rd_eof(r);
-            l = 0;
-            act = ACT_NONE;
-        }
-        r.w >>= l;
-        r.have -= l;
-        u32 sym = e >> 4;
-
-        /* ---- extra bits: insert + copy (command), distance extra, none (literal) ---- */
-        u64 ce = cmd_tab[sym < 704 ? sym : 0];
-        u32 iext = ((u32)ce >> 16) & 0xff, cext = (u32)(ce >> 40);
-        u32 dn = sym - c.direct - 16; /* distance symbols past the ring and direct codes */
-        bool dlong = act == ST_DIST && sym >= 16 + c.direct;
-        u32 dx = 1 + (dn >> (c.postfix + 1));
-        dx = dx > 25 ? 25 : dx; /* only after a read failure */
-        /* two fields at most: insert then copy extra bits, or the distance extra bits */
-        u32 n1 = act == ST_CMD ? iext : dlong ? dx : 0, n2 = act == ST_CMD ? cext : 0;
-        if (n1 > r.have)
-            refill_mid();
-        if (n1 > r.have) {
-            rd_eof(r);
-            n1 = n2 = 0;
-            act = ACT_NONE;
-        }
-        u32 x1 = (u32)r.w & ((1u << n1) - 1);
-        r.w >>= n1;
-        r.have -= n1;
-        if (n2 > r.have)
-            refill_mid();
-        if (n2 > r.have) {
-            rd_eof(r);
-            n2 = 0;
-            act = ACT_NONE;
-        }
-        u32 x2 = (u32)r.w & ((1u << n2) - 1);
-        r.w >>= n2;
-        r.have -= n2;
-
-        YS_MARK(t_s2);
-        bool do_copy = false;
-        i64 dist = c.r0;
-        if (act == ST_CMD) {
-            insert = ((u32)ce & 0xffff) + x1;
-            copy = ((u32)(ce >> 24) & 0xffff) + x2;
-            if (insert > mlen) {
-                rd_fail(r, YS_INVALID); /* :1189 */
-                insert = 0;
-            }
-            mlen -= insert;
-            implicit = sym < 128;
-            st = insert ? (u32)ST_LIT : implicit ? (u32)ST_COPY : (u32)ST_DIST;
-        } else if (act == ST_LIT) {
-            rb[ring_at<S>(slot, (u32)(u64)c.outp)] = (u8)sym;
-            c.outp++;
-            maxd = maxd < c.wsize ? maxd + 1 : maxd;
-            c.p2 = c.p1;
-            c.p1 = sym;
-            if (--insert == 0) {
-                st = mlen == 0 ? (u32)ST_END : implicit ? (u32)ST_COPY : (u32)ST_DIST; /* :1227 */
-            }
-        }
-        YS_MARK(t_s3);
-        if (odd) {
-        if (act == ST_COPY)
-            do_copy = true; /* the distance is the newest one of the ring */
-        else if (act == ST_DIST) { /* distance(): yeast.c:761-789 */
-            u32 ds = sym;
-            if (ds < 16) {
-                u32 back = ds < 4 ? ds : ds < 10 ? 0 : 1;
-                u32 rv = back == 0 ? c.r0 : back == 1 ? c.r1 : back == 2 ? c.r2 : c.r3;
-                u32 k = ds < 10 ? ds - 4 : ds - 10; /* -1 +1 -2 +2 -3 +3 */
-                int dl = (int)(k >> 1) + 1;
-                dl = (k & 1) ? dl : -dl;
-                dl = ds < 4 ? 0 : dl;
-                dist = (i64)rv + dl;
-            } else if (!dlong)
-                dist = ds - 15;
-            else {
-                u64 o2 = ((u64)(2 + ((dn >> c.postfix) & 1)) << dx) - 4;
-                dist = (i64)(((o2 + x1) << c.postfix) + (dn & ((1u << c.postfix) - 1)) + c.direct + 1);
-            }
-            if (ds && dist > 0 && dist <= (i64)maxd) {
-                c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
-            }
-            do_copy = true;
-        }
-        if (do_copy && !r.rc) {
-            /* validate and account for the copy now; queue the byte moving */
-            u32 rel = (u32)(c.outp - mb_base), nout = 0, ref = 0, kind = K_FAR;
-            if (dist <= 0) {
-                rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
-            } else if (dist > (i64)maxd) {
-                DictRef dr;
-                u64 id = (u64)dist - maxd - 1;
-                if (!dict_prepare(c, copy, id, dr) || dr.total > mlen) {
-                    rd_fail(r, YS_INVALID); /* :921-930, :1269 */
-                } else {
-                    nout = dr.total;
-                    kind = K_DICT;
-                    ref = (dr.xform << 25) | (dr.wlen << 20) | (u32)(dr.w + dr.wskip - c.dict);
-                    if (ctx && nout) {
-                        /* last two bytes of the transformed word: suffix and prefix bytes are in
-                           LDS; raw dictionary bytes are fetched (arriving with the next lookup);
-                           the few cases that need the uppercase rules wait for the drain */
-                        if (dr.slen >= 2) {
-                            u64 sf = c.sh->xsuf[dr.xform] >> (8 * (dr.slen - 2));
-                            c.p2 = (u32)sf & 255;
-                            c.p1 = (u32)(sf >> 8) & 255;
-                            stale = 0;
-                        } else if (dr.wlen >= 2 + (1 - dr.slen) && dr.op != 2 && !(dr.op == 1 && dr.wlen < 5)) {
-                            const u8 *we = dr.w + dr.wskip + dr.wlen;
-                            if (dr.slen == 1) {
-                                pn_c = (u32)c.sh->xsuf[dr.xform] & 255;
-                                pn = gld8(we - 1);
-                                pn_valid = 2;
-                            } else {
-                                pn = gld16u(we - 2);
-                                pn_valid = 1;
-                            }
-                            stale = 0;
-                        } else
-                            stale = 1;
-                    }
-                }
-            } else if (copy > mlen) {
-                rd_fail(r, YS_INVALID); /* :1283 */
-            } else {
-                nout = copy;
-                ref = (u32)dist;
-                const u8 *s1 = c.outp - dist + copy; /* end of the source */
-                bool fits = (u32)(c.outp - fl) + copy <= RB;
-                kind = !fits ? (u32)K_SLOW : s1 <= fl ? (u32)K_FAR : (u32)K_BYTES;
-                if (ctx) {
-                    /* the last two bytes of the copy, straight from their sources when those are
-                       final already (not behind a queued write): fetched from the output region
-                       (arriving with the next lookup) or read from the ring */
-                    const u8 *first = qn ? mb_base + pend_rel : c.outp;
-                    u32 i1 = copy - 1, i2 = copy - 2;
-                    if ((u32)dist < copy) { /* overlapping: byte i repeats byte i mod dist */
-                        i1 %= (u32)dist;
-                        i2 %= (u32)dist;
-                    }
-                    const u8 *q1 = c.outp - dist + i1, *q2 = c.outp - dist + i2;
-                    if (q1 >= first || q2 >= first)
-                        stale = 1;
-                    else if (q2 + 1 == q1 && q1 < fl) {
-                        pn = gld16u(q2);
-                        pn_valid = 1;
-                        stale = 0;
-                    } else {
-                        c.p1 = q1 >= fl ? staged(q1) : gld8(q1);
-                        c.p2 = q2 >= fl ? staged(q2) : gld8(q2);
-                        stale = 0;
-                    }
-                }
-            }
-            mlen -= nout;
-            if (nout) {
-                pend_rel = qn ? pend_rel : rel;
-                wl->qa[qn * S + slot] = rel;
-                wl->qb[qn * S + slot] = nout | (kind << 28);
-                wl->qc[qn * S + slot] = ref;
-                qn++;
-            }
-            c.outp += nout;
-            u32 room = c.wsize - maxd;
-            maxd += nout < room ? nout : room;
-            st = mlen ? (u32)ST_CMD : (u32)ST_END;
-        }
-        }
-        st = r.rc ? (u32)ST_END : st;
-        YS_MARK(t_s4);
-        /* second pass, the whole wavefront at once: when some queue is full, some ring is nearly
-           full, or some stream needs bytes that are still queued */
-        bool need = st == ST_LIT && ctx && stale;
-        held = need ? held + 1 : 0;
-        if (__any(qn == FQ || held > YS_HOLD || (u64)(c.outp - fl) > RB - RB_SLACK)) {
-#ifdef YS_PROFILE
-            u64 td0 = __builtin_readcyclecounter();
-            c.n_need += need;
-            c.n_qfull += qn == FQ;
-#endif
-            drain();
-            if (need) {
-                last_two();
-                stale = 0;
-                held = 0;
-            }
-#ifdef YS_PROFILE
-            c.t_drain += __builtin_readcyclecounter() - td0;
-            c.n_drains++;
-            c.t_mark = __builtin_readcyclecounter();
-#endif
-        }
-        if (st == ST_LIT && ctx)
-            offL = next_lit_table();
-        YS_MARK(t_s5);
-    }
-    /* metablock end (or failure): drain what is queued -- everything queued was valid -- and
-       bring the output region up to date */
-    drain();
-    flush(c.outp, true);
-    group_sync_mem();
-    if (pn_valid) {
-        c.p1 = pn_valid == 1 ? pn >> 8 : pn_c;
-        c.p2 = pn & 255;
-    }
-    if (stale) /* context for the next meta-block */
-        last_two();
-}
-
 #include "yeast_lean.h"
 
 /* ------------------------------------------------------------- meta-block */
 
 /* metablock(): yeast.c:971-1308.  Returns ISLAST. */
-template <int G, bool CMP, int FLAT> /* FLAT: 0, or the streams per wavefront of the batch kernel */
+template <int G, bool CMP, int FLAT> /* FLAT: 0, or the streams per wavefront of the batch kernel (G = 1) */
 DEV u32 metablock(Ctx &c, u32 sub)
 {
     Rd &r = c.r;
@@ -1235,9 +568,6 @@ DEV u32 metablock(Ctx &c, u32 sub)
         return 1;
 
     /* ---- header: yeast.c:1078-1159 ---- */
-#ifdef YS_PROFILE
-    u64 tp0 = __builtin_readcyclecounter();
-#endif
     Hdr h;
     h.r = r;
     h.ws = c.ws;
@@ -1428,10 +758,6 @@ DEV u32 metablock(Ctx &c, u32 sub)
             }
         } while (mlen && !r.rc);
     } else {
-#ifdef YS_PROFILE
-        u64 tp1 = __builtin_readcyclecounter();
-        c.t_hdr += tp1 - tp0;
-#endif
         FlatEnv fe;
         fe.itab = itab;
         fe.dtab = dtab;
@@ -1441,25 +767,14 @@ DEV u32 metablock(Ctx &c, u32 sub)
         fe.offD0 = (u32)((const u8 *)tD0 - c.ws);
         fe.cur_mode = cur_mode;
         fe.ctx = ctx;
-        /* meta-blocks without block switching and with one distance code (the usual case for
-           short streams) run a loop that carries none of that machinery; the choice is made
-           for the whole wavefront so the streams stay in one loop */
-        if constexpr (FLAT >= 1000) { /* the lean loop, one stream per lane */
-            bool simple = c.L.num == 1 && c.I.num == 1 && c.D.num == 1;
-            if (__all(simple))
-                run_lean<FLAT >= 1000 ? FLAT - 1000 : 64, true>(c, mlen, fe);
-            else
-                run_lean<FLAT >= 1000 ? FLAT - 1000 : 64, false>(c, mlen, fe);
-        } else {
-            bool simple = c.L.num == 1 && c.I.num == 1 && c.D.num == 1 && c.dist_codes == 1;
-            if (__all(simple))
-                run_flat<G, FLAT && FLAT < 1000 ? FLAT : 64, true>(c, mlen, sub, fe);
-            else
-                run_flat<G, FLAT && FLAT < 1000 ? FLAT : 64, false>(c, mlen, sub, fe);
-        }
-#ifdef YS_PROFILE
-        c.t_loop += __builtin_readcyclecounter() - tp1;
-#endif
+        /* meta-blocks without block switching (the usual case for short streams) run a loop that
+           carries none of that machinery; the choice is made for the whole wavefront so the
+           streams stay in one loop */
+        bool simple = c.L.num == 1 && c.I.num == 1 && c.D.num == 1;
+        if (__all(simple))
+            run_lean<FLAT, true>(c, mlen, fe);
+        else
+            run_lean<FLAT, false>(c, mlen, fe);
     }
     if (!r.rc && last && tail_nonzero(r))
         rd_fail(r, YS_INVALID); /* :1305 */
@@ -1487,11 +802,6 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     c.p1 = c.p2 = 0;
     c.nmeta = 0;
     c.need = 0;
-#ifdef YS_PROFILE
-    c.t_hdr = c.t_loop = c.t_drain = c.t_look = c.t_dload = 0;
-    c.t_s0 = c.t_s2 = c.t_s3 = c.t_s4 = c.t_s5 = c.t_mark = 0;
-    c.n_trips = c.n_drains = c.n_need = c.n_qfull = c.n_rfull = c.n_ents = 0;
-#endif
     c.dict = p.dict;
     c.xf = p.xforms;
     c.xdict = p.xdict;
@@ -1532,16 +842,6 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     /* bytes pulled: every byte when the bit reader ran dry, else ceil(bits/8) (yeast.c:1388) */
     rec.used = c.r.dry ? (s1 - s0) : (rd_pos(c.r) + 7) >> 3;
     rec.check = c.need;
-#ifdef YS_PROFILE
-    rec.check = ((c.t_hdr >> 10) & 0xfffff) | (((c.t_loop >> 10) & 0xfffff) << 20) | (((c.t_drain >> 10) & 0xfffff) << 40);
-    rec.used = (c.t_look >> 10) | ((u64)c.n_trips << 32);
-    rec.flags = c.n_drains;
-    if (sub == 0 && c.cap >= 64) {
-        u64 *prof = (u64 *)c.out; /* the profile build's output bytes are not meant to be looked at */
-        prof[0] = c.t_s0; prof[1] = c.t_look; prof[2] = c.t_s2; prof[3] = c.t_s3; prof[4] = c.t_s4; prof[5] = c.t_s5;
-    }
-    rec.got = (u64)(c.n_need & 0xfff) | ((u64)(c.n_qfull & 0xfff) << 12) | ((u64)(c.n_rfull & 0xfff) << 24) | ((c.t_dload >> 10) << 36);
-#endif
     p.rec[job] = rec;
     if (c.r.rc == YS_WORKSPACE && !p.retry && sub == 0)
         p.retry_list[atomicAdd(p.retry_count, 1u)] = job;

@@ -61,9 +61,10 @@ int yeast_batch(size_t n, void const *const *src, size_t *len, void **dest, size
  *   d_src_off  n+1 offsets: stream i is d_src[d_src_off[i] .. d_src_off[i+1])
  *   d_dst      output arena; stream i may use d_dst[d_dst_off[i] .. d_dst_off[i+1])
  *   d_rec      n records, written by the kernels
- *   lanes_per_stream  0 = library default (by batch size), else 1, 2, 4 (batch kernel) or 8, 16, 64 (cooperative
- *              kernel) lanes of a wavefront cooperate on one stream; 65 = one wavefront per stream with the
- *              stream's prefix-code tables in LDS (lowest latency for batches of a few thousand streams)
+ *   lanes_per_stream  0 = library default (by batch size), else 1 (batch kernel: one stream per lane) or 8, 16, 64
+ *              (cooperative kernel: that many lanes of a wavefront cooperate on one stream); 65 = one wavefront
+ *              per stream with the stream's prefix-code tables in LDS (lowest latency for batches of a few
+ *              thousand streams)
  * Returns 0 or a negative error (see yeast_last_error()).
  */
 int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, void *d_dst, const uint64_t *d_dst_off,

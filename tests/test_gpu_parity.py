@@ -85,12 +85,41 @@ def test_misc_encoder_parameters(lanes, monkeypatch):
         assert "%08x" % r[4] == m["crc32c"]
 
 
-@pytest.mark.parametrize("lanes", [65, 64, 16, 8, 4, 2, 1, -1])
+@pytest.mark.parametrize("lanes", KERNELS)
+def test_synthesised_streams_cfg4(lanes, monkeypatch):
+    # BASELINE config 4 (tools/brosynth.py; expected values from the reference): all 121 transforms at
+    # every word length, the four context modes, NPOSTFIX/NDIRECT, block switching, context map
+    # styles, simple codes, overlapping copies of every short period, stored and metadata blocks
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    meta, streams = H.packed_streams("cfg4_streams")
+    res = ba.yeast_batch(streams, ba.CHECK_XXH64)
+    for m, s, r in zip(meta["streams"], streams, res):
+        assert (r[0], r[2], r[3]) == (m["rc"], m["got"], m["used"]), m["name"]
+        assert "%016x" % r[4] == m["xxh64"], m["name"]
+        assert r[1] == H.oracle_yeast(s)[3], m["name"]
+
+
+@pytest.mark.parametrize("lanes", KERNELS)
+def test_large_window_streams_cfg5(lanes, monkeypatch):
+    # BASELINE config 5: window bits 24 with 16 MiB back-references and copies of megabytes (single
+    # streams: a latency case); the batch kernel takes the 1 MiB-window one only
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    meta, streams = H.packed_streams("cfg5_streams")
+    for m, s in zip(meta["streams"], streams):
+        if lanes == 1 and m["got"] > (4 << 20):
+            continue
+        (rc, out, got, used, chk), = ba.yeast_batch([s], ba.CHECK_CRC32C)
+        assert (rc, got, used) == (m["rc"], m["got"], m["used"]), m["name"]
+        assert "%08x" % chk == m["crc32c"], m["name"]
+        assert "%016x" % ba.xxh64(out) == m["xxh64"], m["name"]
+
+
+@pytest.mark.parametrize("lanes", [65, 64, 16, 8, 1, -1, -2])
 def test_cfg2_batch_every_group_width(lanes, monkeypatch):
     meta, streams = H.packed_streams("cfg2_streams")
-    if lanes < 0:  # one stream per lane in full wavefronts (the default is half-filled ones, two per SIMD)
+    if lanes < 0:  # one stream per lane in full (-1) or quarter-filled (-2) wavefronts; the default is half-filled
+        monkeypatch.setenv("YEAST_HALF", "0" if lanes == -1 else "2")
         lanes = 1
-        monkeypatch.setenv("YEAST_HALF", "0")
     monkeypatch.setenv("YEAST_LANES", str(lanes))
     many = streams * 9  # 2,304 streams: above the threshold where the batch path picks YEAST_LANES
     res = ba.yeast_batch(many, ba.CHECK_XXH64)

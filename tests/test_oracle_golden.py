@@ -68,6 +68,20 @@ def test_context_tables_match_check_c():
         assert zlib.crc32(ctypes.string_at(o.oracle_context_lut(i), 256)) == want
 
 
+def test_synthesised_streams_cfg4_cfg5():
+    # BASELINE configs 4 and 5: streams from tools/brosynth.py, expected values from the reference
+    # (tools/make_cfg4.py): all transforms x word lengths, context modes, NPOSTFIX/NDIRECT, block
+    # switching, context map styles, overlapping copies, 16 MiB back-references
+    o = H.oracle()
+    for name in ("cfg4_streams", "cfg5_streams"):
+        meta, streams = H.packed_streams(name)
+        for m, s in zip(meta["streams"], streams):
+            rc, got, used, out = H.oracle_yeast(s)
+            assert (rc, got, used) == (m["rc"], m["got"], m["used"]), m["name"]
+            assert "%016x" % o.oracle_xxh64(out, len(out), 0) == m["xxh64"], m["name"]
+            assert "%08x" % o.oracle_crc32c(0, out, len(out)) == m["crc32c"], m["name"]
+
+
 def test_against_real_reference_when_present():
     ref = H.reference()
     if ref is None:

@@ -41,7 +41,7 @@ for m, s in zip(meta["streams"], streams):
     rc, out, got, used = ba.yeast(s)
     chk("misc %s %s" % (m["file"], m["params"]), (rc, got, used, out), H.oracle_yeast(s))
 meta, streams = H.packed_streams("cfg2_streams")
-for lanes in (65, 64, 16, 8, 4, 2, 1):
+for lanes in (65, 64, 16, 8, 1):
     os.environ["YEAST_LANES"] = str(lanes)
     t = time.time()
     res = ba.yeast_batch(streams * 8, ba.CHECK_XXH64)

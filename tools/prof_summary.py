@@ -14,3 +14,21 @@ for f in sorted(glob.glob(os.path.join(base, "**", "*counter_collection.csv"), r
     print("==", f)
     for k, v in agg.items():
         print(k, {a: b for a, b in v.items()})
+
+# HBM traffic of the dominant kernel per launch, for bench.py's roofline.traffic: FETCH_SIZE + WRITE_SIZE
+# (rocprofv3 reports them in KiB; no further correction is applied: the guide's factor of two for
+# FETCH_SIZE is calibrated for 16-byte-per-lane streaming reads, not for this kernel's scattered ones)
+import json
+tot = {}
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(base, "**", "*counter_collection.csv"), recursive=True):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                if r["Counter_Name"] == name and "k_decode_lean" in r["Kernel_Name"]]
+        if vals:
+            tot[name] = sum(vals) / len(vals) * 1024.0
+if len(tot) == 2 and len(sys.argv) > 2:
+    out = {"streams": int(sys.argv[2]), "kernel": "k_decode_lean<32>", "fetch_bytes": tot["FETCH_SIZE"],
+           "write_bytes": tot["WRITE_SIZE"], "bytes_per_launch": tot["FETCH_SIZE"] + tot["WRITE_SIZE"],
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB x 1024, mean over launches"}
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "hbm_traffic.json"), "w"), indent=1)
+    print("hbm_traffic.json:", out)
