@@ -41,7 +41,7 @@ def build_order(n, ndistinct, seed, kind="shuffled"):
     kind "wave" (64 consecutive copies of one stream) and "same" (one stream only) are diagnostic
     layouts that remove lane divergence; the bench line is always quoted on "shuffled"."""
     if kind == "wave":
-        return (np.arange(n) // 64) % ndistinct
+        return (np.arange(n) // 64 * 7) % ndistinct
     if kind == "same":
         return np.zeros(n, dtype=np.int64)
     rng = np.random.RandomState(seed)

@@ -49,6 +49,8 @@ typedef struct {
     u32 *counter;        /* work-queue head, zeroed before launch */
     u32 *retry_count;    /* number of streams queued for the large-arena pass */
     u32 *retry_list;     /* their indices (n entries) */
+    const u32 *order;    /* batch kernel: the streams in the order they are handed out (longest first), or null */
+    u32 debug;           /* measurement aids of the batch kernel (YEAST_DEBUG), never set in normal use */
     u32 retry;           /* 0: first pass over all n streams; 1: pass over retry_list */
     u32 n;
     const u8 *dict;      /* 122,784-byte static dictionary */

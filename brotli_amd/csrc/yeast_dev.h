@@ -22,6 +22,17 @@ DEV u64 gld64u(const void *p) /* unaligned */
     typedef u64 __attribute__((aligned(1))) u64u;
     return *(const GAS u64u *)p;
 }
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+DEV u32x4 gld128u(const void *p) /* unaligned */
+{
+    typedef u32x4 __attribute__((aligned(1))) u32x4u;
+    return *(const GAS u32x4u *)p;
+}
+DEV void gst128u(void *p, u32x4 v)
+{
+    typedef u32x4 __attribute__((aligned(1))) u32x4u;
+    *(GAS u32x4u *)p = v;
+}
 DEV u32 gld16u(const void *p) /* unaligned */
 {
     typedef u16 __attribute__((aligned(1))) u16u;

@@ -28,6 +28,7 @@ int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned
 int ysl_upload_constants(const u8 *lut768);
 int ysl_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base, u8 *xdict, void *stream);
 int ysl_launch(const ys_params *p, int half, unsigned streams, void *stream);
+int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *order, void *stream);
 int ysw_upload_constants(const u8 *lut768);
 unsigned ysw_shared_bytes(void);
 int ysw_launch(const ys_params *p, unsigned slot_entries, unsigned rootcaps, unsigned blocks, void *stream);
@@ -261,10 +262,12 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         snprintf(t_err, sizeof(t_err), "libyeast_mi355x: lanes_per_stream must be 1, 8, 16, 64 or 65");
         return -1;
     }
-    /* counters: [0] main queue head, [1] retry queue head, [2] retry count; then the retry list */
-    if (grow(d.ctr, 16 + n * sizeof(u32)))
+    /* counters: [0] main queue head, [1] retry queue head, [2] retry count; then the size-class
+       counters of the hand-out order, the retry list and the hand-out order */
+    const size_t order_bins = 1024;
+    if (grow(d.ctr, 16 + order_bins * sizeof(u32) + 2 * n * sizeof(u32)))
         return -1;
-    HIPCK(hipMemsetAsync(d.ctr.p, 0, 16, st));
+    HIPCK(hipMemsetAsync(d.ctr.p, 0, 16 + order_bins * sizeof(u32), st));
     ys_params p;
     memset(&p, 0, sizeof(p));
     p.src = src;
@@ -274,7 +277,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     p.rec = rec;
     p.counter = (u32 *)d.ctr.p;
     p.retry_count = (u32 *)d.ctr.p + 2;
-    p.retry_list = (u32 *)d.ctr.p + 4;
+    p.retry_list = (u32 *)d.ctr.p + 4 + order_bins;
     p.retry = 0;
     p.n = (u32)n;
     p.dict = d.d_dict;
@@ -338,7 +341,17 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
                  rd = (unsigned)env_int("YEAST_LEAN_ROOT_DIST", 7);
         auto clamp = [](unsigned v) { return v < 4 ? 4u : v > 8 ? 8u : v; };
         p.rootcaps = 8u | (clamp(rl) << 8) | (clamp(ri) << 16) | (clamp(rd) << 24);
+        if (env_int("YEAST_SORT", 1)) { /* hand the streams out by size class, longest first (yeast_lane.hip) */
+            u32 *order = p.retry_list + n;
+            e = ysl_order(soff, (unsigned)n, (u32 *)d.ctr.p + 4, order, st);
+            if (e)
+                return fail("hand-out order launch", (hipError_t)e);
+            p.order = order;
+        }
+        p.debug = (u32)env_int("YEAST_DEBUG", 0);
         e = ysl_launch(&p, half, groups, st);
+        p.order = nullptr;
+        p.debug = 0;
     }
     else
         e = ys_launch_decode(&p, lanes, cmp, groups, st);

@@ -22,6 +22,8 @@ __global__ __launch_bounds__(256, 64 / S) void k_decode_lean(ys_params p)
     u32 wave = (blockIdx.x * blockDim.x + lane) >> 6;
     u32 slot = lane & 63;
     u8 *ws = p.ws + (u64)(wave * S + (slot < S ? slot : 0)) * p.ws_stride;
+    if (p.debug & 1) /* every stream of the wavefront uses one workspace: only meaningful when they are copies of one stream */
+        ws = p.ws + (u64)(wave * S) * p.ws_stride;
     const u32 limit = p.retry ? *p.retry_count : p.n;
     for (;;) {
         u32 base = 0;
@@ -34,6 +36,8 @@ __global__ __launch_bounds__(256, 64 / S) void k_decode_lean(ys_params p)
         if (slot < S && job < limit) {
             if (p.retry)
                 job = p.retry_list[job];
+            else if (p.order)
+                job = p.order[job];
             decode_stream<1, false, S>(p, job, ws, &sh, 0, &wlds[lane >> 6]);
         }
     }
@@ -60,6 +64,61 @@ __global__ __launch_bounds__(256) void k_expand_dict(const u8 *dict, const u8 *x
             dict_write_exact(d, xdict + sh.xbase[t * YS_XD_LENS + L - 4] + i * d.total);
         }
     }
+}
+
+/* Hand-out order of the batch kernel.  The streams of a wavefront run until the longest of them is
+   done, and the work of a stream follows its compressed size closely (correlation 0.999 on the
+   text batch), so streams are handed out by size class, longest first: a wavefront gets streams
+   of one class (5 bits of mantissa: classes are 3 % wide) and the last wavefronts get the
+   shortest.  Three small launches: class histogram, scan, scatter.  The order inside a class is
+   whatever the atomics give; results do not depend on it. */
+#define YS_ORDER_BINS 1024
+DEV u32 order_bin(u64 len)
+{
+    u32 l = len > 0xffffffffull ? 0xffffffffu : (u32)len;
+    u32 key = l;
+    if (l >= 32) {
+        u32 e = 31 - __builtin_clz(l);
+        key = ((e - 4) << 5) | ((l >> (e - 5)) & 31);
+    }
+    return YS_ORDER_BINS - 1 - key; /* key <= 27 * 32 + 31 */
+}
+__global__ void k_order_hist(const u64 *src_off, u32 n, u32 *bins)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        atomicAdd(bins + order_bin(src_off[i + 1] - src_off[i]), 1u);
+}
+__global__ __launch_bounds__(YS_ORDER_BINS) void k_order_scan(u32 *bins)
+{
+    __shared__ u32 t[YS_ORDER_BINS];
+    u32 i = threadIdx.x, v = bins[i];
+    t[i] = v;
+    __syncthreads();
+    for (u32 o = 1; o < YS_ORDER_BINS; o <<= 1) {
+        u32 a = i >= o ? t[i - o] : 0;
+        __syncthreads();
+        t[i] += a;
+        __syncthreads();
+    }
+    bins[i] = t[i] - v; /* exclusive */
+}
+__global__ void k_order_scatter(const u64 *src_off, u32 n, u32 *bins, u32 *order)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        order[atomicAdd(bins + order_bin(src_off[i + 1] - src_off[i]), 1u)] = i;
+}
+
+/* bins: YS_ORDER_BINS zeroed counters; order: n entries */
+extern "C" int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *order, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    unsigned blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_order_hist, dim3(blocks), dim3(256), 0, st, src_off, n, bins);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(YS_ORDER_BINS), 0, st, bins);
+    hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(256), 0, st, src_off, n, bins, order);
+    return (int)hipGetLastError();
 }
 
 extern "C" int ysl_upload_constants(const u8 *lut768) { return ys_upload_constants_impl(lut768); }
