@@ -83,11 +83,21 @@ DEV u32 order_bin(u64 len)
     }
     return YS_ORDER_BINS - 1 - key; /* key <= 27 * 32 + 31 */
 }
-__global__ void k_order_hist(const u64 *src_off, u32 n, u32 *bins)
+/* both counting kernels count inside the block first (LDS atomics) and touch a global counter once
+   per block and class: 65,536 streams fall into a few dozen classes */
+__global__ __launch_bounds__(256) void k_order_hist(const u64 *src_off, u32 n, u32 *bins)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ u32 cnt[YS_ORDER_BINS];
+    for (u32 k = threadIdx.x; k < YS_ORDER_BINS; k += 256)
+        cnt[k] = 0;
+    __syncthreads();
+    u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i < n)
-        atomicAdd(bins + order_bin(src_off[i + 1] - src_off[i]), 1u);
+        atomicAdd(cnt + order_bin(src_off[i + 1] - src_off[i]), 1u);
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < YS_ORDER_BINS; k += 256)
+        if (cnt[k])
+            atomicAdd(bins + k, cnt[k]);
 }
 __global__ __launch_bounds__(YS_ORDER_BINS) void k_order_scan(u32 *bins)
 {
@@ -103,11 +113,24 @@ __global__ __launch_bounds__(YS_ORDER_BINS) void k_order_scan(u32 *bins)
     }
     bins[i] = t[i] - v; /* exclusive */
 }
-__global__ void k_order_scatter(const u64 *src_off, u32 n, u32 *bins, u32 *order)
+__global__ __launch_bounds__(256) void k_order_scatter(const u64 *src_off, u32 n, u32 *bins, u32 *order)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ u32 cnt[YS_ORDER_BINS];
+    for (u32 k = threadIdx.x; k < YS_ORDER_BINS; k += 256)
+        cnt[k] = 0;
+    __syncthreads();
+    u32 i = blockIdx.x * 256 + threadIdx.x, b = 0, rank = 0;
+    if (i < n) {
+        b = order_bin(src_off[i + 1] - src_off[i]);
+        rank = atomicAdd(cnt + b, 1u);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < YS_ORDER_BINS; k += 256)
+        if (cnt[k])
+            cnt[k] = atomicAdd(bins + k, cnt[k]); /* the block's first place in the class */
+    __syncthreads();
     if (i < n)
-        order[atomicAdd(bins + order_bin(src_off[i + 1] - src_off[i]), 1u)] = i;
+        order[cnt[b] + rank] = i;
 }
 
 /* bins: YS_ORDER_BINS zeroed counters; order: n entries */

@@ -26,6 +26,10 @@
 #ifndef YEAST_LEAN_H
 #define YEAST_LEAN_H
 
+#ifndef YS_LIT_SLOTS
+#define YS_LIT_SLOTS 2 /* literals a stream can decode per pass */
+#endif
+
 /* per-wavefront LDS: [index][stream], so the streams of a wavefront use different banks */
 template <int S>
 struct LeanLds {
@@ -46,7 +50,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
     const u32 slot = threadIdx.x & 63;
     const bool ctx = fe.ctx;
     const u64 *cmd_tab = c.sh->cmd;
-    const u8 *lut = c.sh->lut;
+    const u32 *kcls = c.sh->kcls;
     u8 *const ws = c.ws;
     u8 *const out_end = c.out + c.cap;
     u32 cur_mode = fe.cur_mode;
@@ -80,6 +84,8 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
     u32 link = 0;    /* first half of a long code of the state the stream is in */
     u32 insert = 0, copy = 0, implicit = 0;
     i32 dist = 0;
+    /* the last two output bytes as their class words (Shared.kcls): everything context_id() needs */
+    u32 k1 = kcls[c.p1 & 255], k2 = kcls[c.p2 & 255];
     u64 got0 = got_of(c);
     u32 maxd = got0 > c.wsize ? c.wsize : (u32)got0;
     /* input: the window r.w and the next two words, requested ahead of their use */
@@ -285,10 +291,9 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                 u32 lo = ki == 0 ? pv.x : ki == 1 ? pv.y : ki == 2 ? pv.z : pv.w;
                 u32 hi = ki == 0 ? pv.y : ki == 1 ? pv.z : ki == 2 ? pv.w : 0;
                 u32 pe = __builtin_amdgcn_alignbyte(hi, lo, k & 3);
-                u32 b2 = pn >= 2 ? pe & 255 : c.p1;
-                u32 b1 = pn >= 2 ? (pe >> 8) & 255 : pv.x & 255;
-                c.p1 = b1;
-                c.p2 = b2;
+                u32 nk2 = kcls[pe & 255], nk1 = kcls[pn >= 2 ? (pe >> 8) & 255 : pv.x & 255];
+                k2 = pn >= 2 ? nk2 : k1;
+                k1 = nk1;
                 pn = 0;
             }
             bool ok = decode(on, e, rootI);
@@ -321,19 +326,14 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
         LMARK(3);
         /* ---- (B) a literal, twice ---- */
 #pragma unroll
-        for (int rep = 0; rep < 2; rep++) {
+        for (int rep = 0; rep < YS_LIT_SLOTS; rep++) {
             const bool on = st == ST_LIT;
-            if (on && ctx) { /* context_id(): yeast.c:698-755 */
-                u32 cid;
-                if (cur_mode == 0)
-                    cid = c.p1 & 0x3f;
-                else if (cur_mode == 1)
-                    cid = c.p1 >> 2;
-                else if (cur_mode == 2)
-                    cid = lut[c.p1] | lut[256 + c.p2];
-                else
-                    cid = ((u32)lut[512 + c.p1] << 3) | lut[512 + c.p2];
-                offL = (u32)wl->lt[cid * S + slot] << 4;
+            if (ctx) { /* context_id(): yeast.c:698-755, from the class words, without branches */
+                u32 c0 = (k1 >> 24) & 63, c1 = k1 >> 26;
+                u32 c2 = (k1 & 63) | ((k2 >> 8) & 3), c3 = ((k1 >> 13) & 0x38) | ((k2 >> 16) & 7);
+                u32 cid = cur_mode < 2 ? (cur_mode == 0 ? c0 : c1) : (cur_mode == 2 ? c2 : c3);
+                u32 o = (u32)wl->lt[cid * S + slot] << 4;
+                offL = on ? o : offL;
             }
             u32 e = lookup(on, offL, rootL);
             LMARK(4);
@@ -345,8 +345,8 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                 gst8(c.outp, sym);
                 c.outp++;
                 maxd = maxd < c.wsize ? maxd + 1 : maxd;
-                c.p2 = c.p1;
-                c.p1 = sym;
+                k2 = k1;
+                k1 = kcls[sym & 255];
                 if (--insert == 0) {
                     if (mlen == 0)
                         st = ST_END; /* :1227 */

@@ -24,6 +24,7 @@ struct Shared {
     u32 xf[128]; /* first word of each transform record: op | omit << 8 | prefix len << 16 | suffix len << 24 */
     u64 xpre[128], xsuf[128]; /* prefix and suffix bytes of each transform, little endian */
     u32 xbase[121 * 21];      /* expanded dictionary: offset of (transform, word length) */
+    u32 kcls[256];            /* per byte value b: lut0[b] | lut1[b] << 8 | lut2[b] << 16 | b << 24 (literal contexts) */
 };
 
 DEV void shared_fill(Shared &sh, const u8 *xforms, const u32 *xbase = nullptr)
@@ -35,6 +36,8 @@ DEV void shared_fill(Shared &sh, const u8 *xforms, const u32 *xbase = nullptr)
         sh.cmd[i] = c_cmd_tab[i];
     for (u32 i = threadIdx.x; i < 768; i += blockDim.x)
         sh.lut[i] = c_ctx_lut[i];
+    for (u32 i = threadIdx.x; i < 256; i += blockDim.x)
+        sh.kcls[i] = (u32)c_ctx_lut[i] | ((u32)c_ctx_lut[256 + i] << 8) | ((u32)c_ctx_lut[512 + i] << 16) | (i << 24);
     if (threadIdx.x < 32)
         sh.dict[threadIdx.x] = c_dict_tab[threadIdx.x];
     if (threadIdx.x < 128) {

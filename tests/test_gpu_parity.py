@@ -114,9 +114,12 @@ def test_large_window_streams_cfg5(lanes, monkeypatch):
         assert "%016x" % ba.xxh64(out) == m["xxh64"], m["name"]
 
 
-@pytest.mark.parametrize("lanes", [65, 64, 16, 8, 1, -1, -2])
+@pytest.mark.parametrize("lanes", [65, 64, 16, 8, 1, -1, -2, -3])
 def test_cfg2_batch_every_group_width(lanes, monkeypatch):
     meta, streams = H.packed_streams("cfg2_streams")
+    if lanes == -3:  # one stream per lane, streams handed out in batch order instead of by size class
+        monkeypatch.setenv("YEAST_SORT", "0")
+        lanes = 1
     if lanes < 0:  # one stream per lane in full (-1) or quarter-filled (-2) wavefronts; the default is half-filled
         monkeypatch.setenv("YEAST_HALF", "0" if lanes == -1 else "2")
         lanes = 1
