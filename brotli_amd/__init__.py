@@ -7,6 +7,7 @@ reference interface they stand for (paths relative to /root/reference):
   yeast(source, expected=None)    yeast.h:25 / yeast.c:1353  -> (rc, out, used)
   yeast_batch(streams, check)     a loop over yeast.h:25 such as juxt.c:77-93
   crc32c / xxh32 / xxh64          crc32c.c:258, xxhash.c:365, xxhash.c:505
+  broad(br, write=True)           broad.c:142 over a .br file in memory -> (code, data, streams)
 
 There is no CPU decode path: importing works anywhere (so the CPU test tier
 can check that the library loads and exports its symbols), but every compute
@@ -25,9 +26,10 @@ LIB_PATH = os.environ.get("YEAST_LIB") or os.path.join(_HERE, "libyeast_mi355x.s
 CHECK_NONE, CHECK_CRC32C, CHECK_XXH32, CHECK_XXH64 = 0, 1, 2, 3
 SRC_PAD = 32
 
-EXPORTS = [  # every symbol include/yeast.h and include/yeast_batch.h declare
+EXPORTS = [  # every symbol include/yeast.h, include/yeast_batch.h and include/yeast_br.h declare
     "yeast", "yeast_verbosity", "yeast_batch", "yeast_batch_device", "yeast_check_device",
     "crc32c", "XXH32", "XXH64", "yeast_last_error", "yeast_device_count", "yeast_debug_table",
+    "yeast_broad", "yeast_sha256", "yeast_sha256_batch",  # include/yeast_br.h
 ]
 
 
@@ -74,6 +76,11 @@ def lib() -> ctypes.CDLL:
         L.yeast_device_count.restype = ctypes.c_int
         L.yeast_debug_table.restype = ctypes.c_void_p
         L.yeast_debug_table.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+        L.yeast_broad.restype = ctypes.c_int
+        L.yeast_broad.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
+                                  ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+        L.yeast_sha256.restype = ctypes.c_int
+        L.yeast_sha256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
         _lib = L
     return _lib
 
@@ -143,6 +150,26 @@ def xxh32(data: bytes, seed: int = 0) -> int:
 
 def xxh64(data: bytes, seed: int = 0) -> int:
     return lib().XXH64(data, len(data), seed)
+
+
+def broad(br: bytes, write: bool = True) -> Tuple[int, bytes, int]:
+    """broad() of broad.c:142-353 over a .br file held in memory: (code, data written, streams decoded).
+    Codes 0 ok, 2 premature end, 3 invalid format, 4 invalid compressed data, 5 length/check mismatch."""
+    out, n, seg = ctypes.c_void_p(None), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    rc = lib().yeast_broad(br, len(br), ctypes.byref(out), ctypes.byref(n), 1 if write else 0, ctypes.byref(seg))
+    if rc < 0:
+        raise _err("yeast_broad")
+    data = ctypes.string_at(out, n.value) if out.value and n.value else b""
+    _libc.free(out)
+    return rc, data, seg.value
+
+
+def sha256(data: bytes) -> bytes:
+    """SHA-256 on the GPU (the reference: OpenSSL's SHA256(), broad.c:266)."""
+    out = ctypes.create_string_buffer(32)
+    if lib().yeast_sha256(data, len(data), out):
+        raise _err("yeast_sha256")
+    return out.raw
 
 
 def debug_table(which: int) -> bytes:

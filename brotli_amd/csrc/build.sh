@@ -17,11 +17,14 @@ $HIPCC $FLAGS -c yeast_lane.hip -o yeast_lane.o ${YEAST_EXTRA_FLAGS} &
 P5=$!
 $HIPCC $FLAGS -c yeast_host.cpp -o yeast_host.o &
 P3=$!
+$HIPCC $FLAGS -c yeast_br.cpp -o yeast_br.o &
+P6=$!
 gcc -O2 -fPIC -DYS_DATA_DIR="\"$DATA\"" -c yeast_data.c -o yeast_data.o
 wait $P1
 wait $P2
 wait $P3
 wait $P4
 wait $P5
-$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT/libyeast_mi355x.so" yeast_decode.o yeast_wave.o yeast_lane.o yeast_check.o yeast_host.o yeast_data.o
+wait $P6
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT/libyeast_mi355x.so" yeast_decode.o yeast_wave.o yeast_lane.o yeast_check.o yeast_host.o yeast_br.o yeast_data.o
 echo "built $OUT/libyeast_mi355x.so"

@@ -275,3 +275,71 @@ extern "C" int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed
     hipLaunchKernelGGL(k_check_buf, dim3(1), dim3(64), 0, (hipStream_t)stream, p, len, kind, seed, out);
     return (int)hipGetLastError();
 }
+
+/* ---- SHA-256 (FIPS 180-4): the fourth check of the .br format (br-format-v3.txt:153-178; the
+   reference takes it from OpenSSL, broad.c:266, brand.c:241).  The blocks of one message chain, so a
+   message is one lane's work; messages run side by side. */
+static __constant__ u32 c_sha_k[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98,
+    0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786,
+    0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8,
+    0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819,
+    0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a,
+    0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7,
+    0xc67178f2};
+
+__device__ __forceinline__ u32 sha_ror(u32 x, int r) { return (x >> r) | (x << (32 - r)); }
+
+/* message i is p[off[i] .. off[i] + len[i]); digest i goes to out[32 * i ..] */
+__global__ __launch_bounds__(64) void k_sha256(const u8 *p, const u64 *off, const u64 *len, u32 n, u8 *out)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const u8 *m = p + off[i];
+    const u64 bytes = len[i], blocks = (bytes + 9 + 63) / 64;
+    u32 h0 = 0x6a09e667, h1 = 0xbb67ae85, h2 = 0x3c6ef372, h3 = 0xa54ff53a, h4 = 0x510e527f, h5 = 0x9b05688c,
+        h6 = 0x1f83d9ab, h7 = 0x5be0cd19;
+    for (u64 b = 0; b < blocks; b++) {
+        u32 w[16];
+        for (u32 k = 0; k < 16; k++) {
+            u32 v = 0;
+            for (u32 j = 0; j < 4; j++) {
+                u64 at = b * 64 + k * 4 + j;
+                u32 c = at < bytes ? m[at] : at == bytes ? 0x80u : 0u;
+                v = (v << 8) | c;
+            }
+            w[k] = v;
+        }
+        if (b == blocks - 1) {
+            w[14] = (u32)((bytes * 8) >> 32);
+            w[15] = (u32)(bytes * 8);
+        }
+        u32 a = h0, bb = h1, c = h2, d = h3, e = h4, f = h5, g = h6, hh = h7;
+#pragma unroll
+        for (u32 t = 0; t < 64; t++) {
+            if (t >= 16) {
+                u32 w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+                w[t & 15] += (sha_ror(w15, 7) ^ sha_ror(w15, 18) ^ (w15 >> 3)) + w[(t + 9) & 15] +
+                             (sha_ror(w2, 17) ^ sha_ror(w2, 19) ^ (w2 >> 10));
+            }
+            u32 t1 = hh + (sha_ror(e, 6) ^ sha_ror(e, 11) ^ sha_ror(e, 25)) + ((e & f) ^ (~e & g)) + c_sha_k[t] + w[t & 15];
+            u32 t2 = (sha_ror(a, 2) ^ sha_ror(a, 13) ^ sha_ror(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+        }
+        h0 += a; h1 += bb; h2 += c; h3 += d; h4 += e; h5 += f; h6 += g; h7 += hh;
+    }
+    u32 hs[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
+    for (u32 k = 0; k < 8; k++)
+        for (u32 j = 0; j < 4; j++)
+            out[32 * (u64)i + 4 * k + j] = (u8)(hs[k] >> (24 - 8 * j));
+}
+
+extern "C" int ys_launch_sha256(const u8 *p, const u64 *off, const u64 *len, unsigned n, u8 *out, void *stream)
+{
+    if (n == 0)
+        return 0;
+    hipLaunchKernelGGL(k_sha256, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, p, off, len, n, out);
+    return (int)hipGetLastError();
+}

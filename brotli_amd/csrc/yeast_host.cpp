@@ -35,6 +35,7 @@ int ysw_launch(const ys_params *p, unsigned slot_entries, unsigned rootcaps, uns
 int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec, unsigned n, unsigned kind, u64 seed,
                     void *stream);
 int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed, u64 *out, void *stream);
+int ys_launch_sha256(const u8 *p, const u64 *off, const u64 *len, unsigned n, u8 *out, void *stream);
 int yeast_verbosity = 0;
 }
 
@@ -625,6 +626,46 @@ static u64 host_check(const void *buf, size_t len, unsigned kind, u64 seed)
         abort();
     }
     return v;
+}
+
+/* SHA-256 of n host buffers in one launch (one lane per buffer); digests to out[32 * i ..].
+   Returns 0, or -1 when the GPU path is unavailable. */
+extern "C" int yeast_sha256_batch(size_t n, void const *const *buf, const size_t *len, unsigned char *out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Device *d;
+    if (n == 0)
+        return 0;
+    if (n > 0x7fffffffu || device_get(&d))
+        return -1;
+    std::vector<u64> meta(2 * n); /* offsets, then lengths */
+    u64 tot = 0;
+    for (size_t i = 0; i < n; i++) {
+        meta[i] = tot;
+        meta[n + i] = len[i];
+        tot += len[i];
+    }
+    size_t meta_at = (tot + 63) & ~(size_t)63, out_at = meta_at + 16 * n;
+    if (grow(d->scratch, out_at + 32 * n))
+        return -1;
+    u8 *base = (u8 *)d->scratch.p;
+    for (size_t i = 0; i < n; i++)
+        if (len[i])
+            HIPCK(hipMemcpyAsync(base + meta[i], buf[i], len[i], hipMemcpyHostToDevice, nullptr));
+    HIPCK(hipMemcpyAsync(base + meta_at, meta.data(), 16 * n, hipMemcpyHostToDevice, nullptr));
+    int e = ys_launch_sha256(base, (const u64 *)(base + meta_at), (const u64 *)(base + meta_at) + n, (unsigned)n,
+                             base + out_at, nullptr);
+    if (e)
+        return fail("sha256 launch", (hipError_t)e);
+    HIPCK(hipMemcpy(out, base + out_at, 32 * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int yeast_sha256(const void *buf, size_t len, unsigned char out[32])
+{
+    const void *b[1] = {buf};
+    size_t l[1] = {len};
+    return yeast_sha256_batch(1, b, l, out);
 }
 
 extern "C" uint32_t crc32c(uint32_t crc, void const *buf, size_t len)

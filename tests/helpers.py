@@ -31,6 +31,10 @@ def oracle():
         L.oracle_dict_word.restype = ctypes.c_int
         L.oracle_dict_word.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
         L.oracle_context_lut.restype = ctypes.c_void_p
+        L.oracle_broad.restype = ctypes.c_int
+        L.oracle_broad.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
+                                   ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+        L.oracle_sha256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
         _oracle = L
     return _oracle
 
@@ -93,3 +97,29 @@ def packed_streams(name):
     meta = load_json(name + ".json")
     blob = open(os.path.join(GOLD, name + ".bin"), "rb").read()
     return meta, [blob[m["off"]:m["off"] + m["len"]] for m in meta["streams"]]
+
+
+def oracle_broad(br: bytes):
+    """oracle/br_oracle.c: (code, data written, streams decoded) -- the shape of brotli_amd.broad()."""
+    out, n, seg = ctypes.c_void_p(None), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    rc = oracle().oracle_broad(br, len(br), ctypes.byref(out), ctypes.byref(n), ctypes.byref(seg))
+    data = ctypes.string_at(out, n.value) if out.value and n.value else b""
+    _libc.free(out)
+    return rc, data, seg.value
+
+
+def br_cases():
+    """tests/golden/br_streams.*: (case, .br bytes); damaged copies are stored as recipes on a base case."""
+    meta = load_json("br_streams.json")
+    blob = open(os.path.join(GOLD, "br_streams.bin"), "rb").read()
+    byname = {c["name"]: c for c in meta["cases"]}
+
+    def data_of(c):
+        if "base" in c:
+            b = bytearray(data_of(byname[c["base"]]))
+            if c["op"] == "xor":
+                b[c["pos"]] ^= c["mask"]
+                return bytes(b)
+            return bytes(b[:c["pos"]])
+        return blob[c["off"]:c["off"] + c["len"]]
+    return [(c, data_of(c)) for c in meta["cases"]]

@@ -227,3 +227,24 @@ def test_reference_harnesses_linked_against_the_drop_in():
     assert p.returncode == 0
     assert b"yeast() returned" not in p.stderr, p.stderr[-400:]
     assert p.stderr.count(b":\n") == 17
+
+
+def test_br_container_reader_every_fixture():
+    # broad() (broad.c:142-353) on the batch decoder.  Every case against this repo's
+    # restatement (code, bytes written, streams decoded) and, where the reference's behaviour is
+    # defined, against the reference's own verdict; hand-made, merged, damaged and truncated files.
+    import hashlib
+    cases = H.br_cases()
+    for k, (c, data) in enumerate(cases):
+        big = c["out_len"] > 100000 or len(data) > 100000
+        if c["name"].startswith(("damage/", "cut/")) and (k % 3 and not big):
+            continue  # a third of the small damaged files, every large one
+        got = ba.broad(data)
+        assert got == H.oracle_broad(data), c["name"]
+        if not c.get("reference_undefined"):
+            assert (got[0], len(got[1])) == (c["rc"], c["out_len"]), c["name"]
+            assert "%016x" % ba.xxh64(got[1]) == c["out_xxh64"], c["name"]
+    for msg in (b"", b"abc", b"a" * 55, b"a" * 56, b"a" * 64, bytes(range(256)) * 999):
+        assert ba.sha256(msg) == hashlib.sha256(msg).digest()
+    c, data = [x for x in cases if x[0]["name"] == "multi/text-12x64KiB"][0]
+    assert ba.broad(data, write=False) == (0, b"", 12)

@@ -10,7 +10,7 @@ import helpers as H
 
 def declared_symbols():
     syms = set()
-    for h in ("yeast.h", "yeast_batch.h"):
+    for h in ("yeast.h", "yeast_batch.h", "yeast_br.h"):
         txt = open(os.path.join(H.ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         for m in re.finditer(r"\b(\w+)\s*\(", txt):
