@@ -8,6 +8,8 @@ reference interface they stand for (paths relative to /root/reference):
   yeast_batch(streams, check)     a loop over yeast.h:25 such as juxt.c:77-93
   crc32c / xxh32 / xxh64          crc32c.c:258, xxhash.c:365, xxhash.c:505
   broad(br, write=True)           broad.c:142 over a .br file in memory -> (code, data, streams)
+  brand(stream, opt, name)        brand.c:286 (wrap one stream)          -> (status, .br bytes)
+  braid(files)                    braid.c:341 (merge .br files)          -> (exit status, .br bytes)
 
 There is no CPU decode path: importing works anywhere (so the CPU test tier
 can check that the library loads and exports its symbols), but every compute
@@ -29,7 +31,7 @@ SRC_PAD = 32
 EXPORTS = [  # every symbol include/yeast.h, include/yeast_batch.h and include/yeast_br.h declare
     "yeast", "yeast_verbosity", "yeast_batch", "yeast_batch_device", "yeast_check_device",
     "crc32c", "XXH32", "XXH64", "yeast_last_error", "yeast_device_count", "yeast_debug_table",
-    "yeast_broad", "yeast_sha256", "yeast_sha256_batch",  # include/yeast_br.h
+    "yeast_broad", "yeast_brand", "yeast_braid", "yeast_sha256", "yeast_sha256_batch",  # include/yeast_br.h
 ]
 
 
@@ -79,6 +81,12 @@ def lib() -> ctypes.CDLL:
         L.yeast_broad.restype = ctypes.c_int
         L.yeast_broad.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
                                   ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+        L.yeast_brand.restype = ctypes.c_int
+        L.yeast_brand.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p,
+                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        L.yeast_braid.restype = ctypes.c_int
+        L.yeast_braid.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t),
+                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
         L.yeast_sha256.restype = ctypes.c_int
         L.yeast_sha256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
         _lib = L
@@ -162,6 +170,32 @@ def broad(br: bytes, write: bool = True) -> Tuple[int, bytes, int]:
     data = ctypes.string_at(out, n.value) if out.value and n.value else b""
     _libc.free(out)
     return rc, data, seg.value
+
+
+def brand(stream: bytes, opt: str = "", name: Optional[str] = None) -> Tuple[int, bytes]:
+    """The reference's brand program (brand.c:286-314): wrap one brotli stream -> (status, .br bytes)."""
+    out, n = ctypes.c_void_p(None), ctypes.c_size_t(0)
+    rc = lib().yeast_brand(stream, len(stream), opt.encode(), name.encode() if name is not None else None,
+                           ctypes.byref(out), ctypes.byref(n))
+    if rc < 0:
+        raise _err("yeast_brand")
+    data = ctypes.string_at(out, n.value) if out.value and n.value else b""
+    _libc.free(out)
+    return rc, data
+
+
+def braid(files: Sequence[bytes]) -> Tuple[int, bytes]:
+    """The reference's braid program (braid.c:341-422): merge .br files -> (exit status, .br bytes)."""
+    k = len(files)
+    arr = (ctypes.c_char_p * max(k, 1))(*files)
+    lens = (ctypes.c_size_t * max(k, 1))(*[len(f) for f in files])
+    out, n = ctypes.c_void_p(None), ctypes.c_size_t(0)
+    rc = lib().yeast_braid(k, arr, lens, ctypes.byref(out), ctypes.byref(n))
+    if rc < 0:
+        raise _err("yeast_braid")
+    data = ctypes.string_at(out, n.value) if out.value and n.value else b""
+    _libc.free(out)
+    return rc, data
 
 
 def sha256(data: bytes) -> bytes:

@@ -311,7 +311,10 @@ extern "C" int yeast_broad(const void *br, size_t len, void **out, size_t *out_l
                 src[i] = b + plan[pick[i]].stream;
                 ln[i] = plan[pick[i]].bound - plan[pick[i]].stream;
             }
-            int e = yeast_batch(n, src.data(), ln.data(), dest.data(), got.data(), rc.data(), kind, chk.data());
+            /* verifying only (broad -t): the decoded bytes stay on the device unless SHA-256 needs them */
+            const bool fetch = write || kind == YEAST_CHECK_NONE;
+            int e = yeast_batch(n, src.data(), ln.data(), fetch ? dest.data() : nullptr, got.data(), rc.data(), kind,
+                                chk.data());
             if (e) {
                 for (void *p : dest)
                     free(p);
@@ -465,4 +468,367 @@ extern "C" int yeast_broad(const void *br, size_t len, void **out, size_t *out_l
     if (segments)
         *segments = nseg;
     return code;
+}
+
+/* ======================================================================== writer and merger
+ * yeast_brand(): brand.c:93-263 (wrap() and main()); yeast_braid(): braid.c:146-422.  Host work is
+ * byte shuffling only: the stream is decoded and its check value computed on the GPU (yeast_batch /
+ * yeast_sha256), header checks and the check of checks through XXH32() of this library.
+ */
+namespace {
+
+void put_var(std::vector<uint8_t> &o, uintmax_t n) /* brand.c:67-76, braid.c:218-225 */
+{
+    while (n > 0x7f) {
+        o.push_back((uint8_t)(n & 0x7f));
+        n >>= 7;
+    }
+    o.push_back((uint8_t)(0x80 | n));
+}
+void put_bvar(std::vector<uint8_t> &o, uintmax_t n) /* brand.c:54-63, braid.c:94-99 */
+{
+    o.push_back((uint8_t)(0x80 | (n & 0x7f)));
+    while ((n >>= 7) > 0x7f)
+        o.push_back((uint8_t)(n & 0x7f));
+    o.push_back((uint8_t)(0x80 | n));
+}
+void put_little(std::vector<uint8_t> &o, uintmax_t v, size_t k) /* brand.c:44-49 */
+{
+    do {
+        o.push_back((uint8_t)v);
+        v >>= 8;
+    } while (--k);
+}
+int hand_over(const std::vector<uint8_t> &o, void **out, size_t *out_len)
+{
+    *out = nullptr;
+    *out_len = o.size();
+    if (o.empty())
+        return 0;
+    *out = malloc(o.size());
+    if (!*out)
+        return 1;
+    memcpy(*out, o.data(), o.size());
+    return 0;
+}
+
+} // namespace
+
+#include <time.h>
+
+extern "C" int yeast_brand(const void *brotli, size_t len, const char *opt, const char *name, void **out,
+                           size_t *out_len)
+{
+    *out = nullptr;
+    *out_len = 0;
+    if (!opt)
+        opt = "";
+    if (!name)
+        name = "filename"; /* brand.c:308 */
+    /* options: brand.c:96-182 */
+    enum { xxh32, xxh64, crc32, sha256 } type = xxh64;
+    size_t check_len = 8;
+    int tail = CONTENT_LEN | CONTENT_OFF, mod = 0, file = 0;
+    for (; *opt; opt++)
+        switch (*opt) {
+        case '1': case '2': case '4': case '8':
+            check_len = (size_t)(*opt - '0');
+            if (type == xxh32 && check_len == 8)
+                type = xxh64;
+            else if (type == xxh64 && check_len < 8)
+                type = xxh32;
+            else if (type == crc32 && check_len == 8)
+                check_len = 4;
+            else if (type == sha256)
+                check_len = 32;
+            break;
+        case 'c':
+            if (check_len > 4)
+                check_len = 4;
+            type = crc32;
+            break;
+        case 's':
+            type = sha256;
+            check_len = 32;
+            break;
+        case 'x':
+            if (check_len > 8)
+                check_len = 8;
+            type = check_len < 8 ? xxh32 : xxh64;
+            break;
+        case 'n': tail = 0; break;
+        case 'u': tail = CONTENT_LEN; break;
+        case 'r': tail = CONTENT_OFF; break;
+        case 'b': tail = CONTENT_LEN | CONTENT_OFF; break;
+        case 'm': mod = 1; break;
+        case 'f': file = 1; break;
+        }
+    /* decode, with the check of the chosen type (brand.c:296-304, 238-250) */
+    const void *src[1] = {brotli};
+    size_t ln[1] = {len}, got[1] = {0};
+    void *dest[1] = {nullptr};
+    int rc[1] = {0};
+    uint64_t chk[1] = {0};
+    unsigned kind = type == xxh64 ? YEAST_CHECK_XXH64 : type == xxh32 ? YEAST_CHECK_XXH32
+                    : type == crc32 ? YEAST_CHECK_CRC32C : YEAST_CHECK_NONE;
+    int e = yeast_batch(1, src, ln, type == sha256 ? dest : nullptr, got, rc, kind, chk);
+    if (e < 0)
+        return e;
+    if (e || rc[0] || ln[0] != len) {
+        free(dest[0]);
+        return 1; /* "error decompressing stream -- aborting" */
+    }
+    uint8_t sha[32];
+    if (type == sha256) {
+        int se = yeast_sha256(dest[0], got[0], sha);
+        free(dest[0]);
+        if (se)
+            return -1;
+    }
+    std::vector<uint8_t> o;
+    o.insert(o.end(), {0xce, 0xb2, 0xcf, 0x81});
+    size_t start = o.size();
+    unsigned mask = type == xxh64 ? 3u : type == xxh32 ? (check_len == 4 ? 2u : check_len == 2 ? 1u : 0u)
+                    : type == crc32 ? (check_len == 4 ? 6u : check_len == 2 ? 5u : 4u) : 7u;
+    mask |= CONTENT_EXTRA; /* brand.c:207: the name is never null there */
+    o.push_back((uint8_t)(mask ^ parity(mask)));
+    if ((mask & 7) == 7)
+        o.push_back(0);
+    {
+        unsigned extra = (mod ? EXTRA_MOD : 0) | (file ? EXTRA_NAME : 0);
+        o.push_back((uint8_t)(extra ^ parity(extra)));
+        if (mod)
+            put_var(o, ((uintmax_t)time(nullptr) + 35) << 1);
+        if (file) {
+            size_t nl = strlen(name);
+            put_var(o, nl);
+            o.insert(o.end(), (const uint8_t *)name, (const uint8_t *)name + nl);
+        }
+    }
+    o.insert(o.end(), (const uint8_t *)brotli, (const uint8_t *)brotli + len);
+    if (type == sha256)
+        o.insert(o.end(), sha, sha + 32);
+    else
+        put_little(o, chk[0], check_len);
+    size_t writ = o.size() - start;
+    unsigned t = (unsigned)tail | 7 | CONTENT_TRAIL;
+    t ^= parity(t);
+    o.push_back((uint8_t)t);
+    if (t & CONTENT_OFF)
+        put_bvar(o, writ);
+    if (t & CONTENT_LEN)
+        put_bvar(o, got[0]);
+    if (t & (CONTENT_OFF | CONTENT_LEN))
+        o.push_back((uint8_t)t);
+    return hand_over(o, out, out_len);
+}
+
+namespace {
+
+/* scan(): braid.c:146-202 over a buffer.  The offsets of the headers and of the trailer, front to
+   back; throws the reference's codes. */
+std::vector<size_t> braid_scan(const uint8_t *b, size_t len)
+{
+    if (len < 4 || memcmp(b, "\xce\xb2\xcf\x81", 4))
+        throw Fail{2};
+    int64_t at = (int64_t)len;
+    auto rget1 = [&]() -> unsigned { /* braid.c:33-41 */
+        if (at == 0)
+            throw Fail{1};
+        return b[--at];
+    };
+    auto rbvar = [&]() -> uintmax_t { /* braid.c:44-54 */
+        unsigned ch = rget1();
+        if ((ch & 0x80) == 0)
+            throw Fail{3};
+        uintmax_t v = ch & 0x7f;
+        do {
+            ch = rget1();
+            v = (v << 7) | (ch & 0x7f);
+        } while ((ch & 0x80) == 0);
+        return v;
+    };
+    unsigned trail;
+    while ((trail = rget1()) == 0)
+        ;
+    if (parity(trail) || !(trail & CONTENT_TRAIL) || (trail & CONTENT_EXTRA))
+        throw Fail{3};
+    if ((trail & CONTENT_CHECK) != 7) {
+        int64_t n = (int64_t)1 << (trail & 3);
+        if (at < n)
+            throw Fail{1};
+        at -= n;
+    }
+    if (trail & CONTENT_LEN)
+        (void)rbvar();
+    int64_t dist = 0;
+    if (trail & CONTENT_OFF)
+        dist = (int64_t)rbvar();
+    if (trail != (CONTENT_TRAIL | 7))
+        if (rget1() != trail)
+            throw Fail{3};
+    if (at > 4 && !(trail & CONTENT_OFF))
+        throw Fail{4};
+    std::vector<size_t> rev;
+    rev.push_back((size_t)at);
+    if (dist) {
+        at -= dist;
+        if (at >= 0)
+            rev.push_back((size_t)at);
+    }
+    while (at > 4) {
+        Cursor c{b, (size_t)at, len};
+        unsigned mask;
+        uintmax_t back;
+        try {
+            mask = c.get1();
+            if (parity(mask) || (mask & CONTENT_TRAIL))
+                throw Fail{3};
+            if (!(mask & CONTENT_OFF))
+                throw Fail{4};
+            back = c.getvar();
+        } catch (Fail &f) {
+            throw Fail{f.code == 2 ? 1 : f.code}; /* "premature end of file" is 1 in braid.c:60 */
+        }
+        at -= (int64_t)back;
+        if (at >= 0)
+            rev.push_back((size_t)at);
+    }
+    if (at != 4)
+        throw Fail{3};
+    return std::vector<size_t>(rev.rbegin(), rev.rend());
+}
+
+} // namespace
+
+extern "C" int yeast_braid(size_t n, void const *const *br, const size_t *len, void **out, size_t *out_len)
+{
+    *out = nullptr;
+    *out_len = 0;
+    int ret = 0;
+    unsigned count = 0;       /* brotli streams, up to 2: braid.c:343 */
+    intmax_t total = 0;       /* total uncompressed length or -1 */
+    std::vector<uint8_t> o, checks; /* checks: every check value copied, in order (braid.c:337) */
+    o.insert(o.end(), {0xce, 0xb2, 0xcf, 0x81});
+    size_t last = 0;
+    for (size_t f = 0; f < n; f++) {
+        const uint8_t *b = (const uint8_t *)br[f];
+        const size_t flen = len[f];
+        size_t keep_o = o.size(), keep_c = checks.size(), keep_last = last;
+        unsigned keep_count = count;
+        try {
+            std::vector<size_t> pos = braid_scan(b, flen);
+            bool any = pos.size() > 1;
+            for (size_t k = 0; k + 1 < pos.size(); k++) { /* copy(): braid.c:252-339 */
+                Cursor c{b, pos[k], flen};
+                auto getc_ = [&]() -> unsigned { return c.next < c.len ? c.buf[c.next++] : 0xffu; }; /* EOF reads as -1 */
+                unsigned mask = getc_();
+                if (mask & CONTENT_OFF)
+                    (void)c.getvar();
+                unsigned id = 0;
+                if ((mask & CONTENT_CHECK) == 7)
+                    id = getc_();
+                unsigned extra = 0, strip = 0;
+                bool head = true;
+                if (mask & CONTENT_EXTRA) {
+                    strip = extra = getc_();
+                    if (last)
+                        strip &= ~(unsigned)(EXTRA_MOD | EXTRA_NAME);
+                    if (!(extra & EXTRA_CHECK))
+                        head = false;
+                }
+                size_t here = o.size();
+                if (last)
+                    mask |= CONTENT_OFF;
+                unsigned newmask = mask;
+                if ((strip & 0x67) == 0)
+                    newmask &= ~(unsigned)CONTENT_EXTRA;
+                o.push_back((uint8_t)(newmask ^ parity(newmask)));
+                if (last)
+                    put_var(o, here - last);
+                last = here;
+                if ((mask & CONTENT_CHECK) == 7)
+                    o.push_back((uint8_t)id);
+                if (mask & CONTENT_EXTRA) {
+                    if (strip & 0x67)
+                        o.push_back((uint8_t)(strip ^ parity(strip)));
+                    if (extra & EXTRA_MOD) {
+                        uintmax_t m = c.getvar();
+                        if (strip & EXTRA_MOD)
+                            put_var(o, m);
+                    }
+                    if (extra & EXTRA_NAME) {
+                        uintmax_t nl = c.getvar();
+                        size_t from = c.next;
+                        c.skip(nl);
+                        if (strip & EXTRA_NAME) {
+                            put_var(o, nl);
+                            o.insert(o.end(), b + from, b + c.next);
+                        }
+                    }
+                    if (extra & EXTRA_EXTRA) {
+                        uintmax_t el = c.getvar();
+                        size_t from = c.next;
+                        c.skip(el);
+                        put_var(o, el);
+                        o.insert(o.end(), b + from, b + c.next);
+                    }
+                    if (extra & EXTRA_METHOD)
+                        o.push_back((uint8_t)getc_());
+                    if (extra & EXTRA_CHECK) {
+                        (void)getc_();
+                        (void)getc_();
+                        unsigned x = head ? XXH32(o.data() + here, o.size() - here, 0) & 0xffff : 0;
+                        o.push_back((uint8_t)(x & 0xff));
+                        o.push_back((uint8_t)(x >> 8));
+                    }
+                }
+                size_t cn = (mask & CONTENT_CHECK) == 7 ? 32 : (size_t)1 << (mask & 3);
+                if (pos[k + 1] < c.next + cn || pos[k + 1] > flen)
+                    throw Fail{1};
+                o.insert(o.end(), b + c.next, b + pos[k + 1]);
+                checks.insert(checks.end(), b + pos[k + 1] - cn, b + pos[k + 1]);
+                if (count < 2)
+                    count++;
+            }
+            if (total != -1) { /* braid.c:372-381 */
+                Cursor c{b, pos.back(), flen};
+                unsigned trail = c.get1();
+                if (trail & CONTENT_LEN) {
+                    if (trail & CONTENT_OFF)
+                        (void)c.getbvar();
+                    total += (intmax_t)c.getbvar();
+                } else if (any)
+                    total = -1;
+            }
+        } catch (Fail &) { /* "-- skipping": braid.c:392-396 */
+            o.resize(keep_o);
+            checks.resize(keep_c);
+            last = keep_last;
+            count = keep_count;
+            ret = 1;
+        }
+    }
+    /* trailer: braid.c:399-416 */
+    unsigned trail = CONTENT_TRAIL | (count > 1 ? 2u : 7u);
+    if (count == 0)
+        total = -1;
+    if (total != -1)
+        trail |= CONTENT_LEN;
+    if (last)
+        trail |= CONTENT_OFF;
+    trail ^= parity(trail);
+    size_t off = o.size();
+    o.push_back((uint8_t)trail);
+    if (last)
+        put_bvar(o, off - last);
+    if (total != -1)
+        put_bvar(o, (uintmax_t)total);
+    if (count > 1)
+        put_little(o, XXH32(checks.data(), checks.size(), 0), 4);
+    if (trail != (CONTENT_TRAIL | 7))
+        o.push_back((uint8_t)trail);
+    if (hand_over(o, out, out_len))
+        return 1;
+    return ret;
 }

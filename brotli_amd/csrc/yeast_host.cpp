@@ -483,8 +483,12 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
         if (cmp)
             cap[i] = have;
         else {
+            /* the first meta-block's length, or four times the compressed size (text compresses about
+               3:1) if that is more: streams of several meta-blocks then rarely need a second pass */
             u64 g = first_mlen_guess((const u8 *)src[i], len[i]);
             u64 c = g ? g : 65536;
+            if (c < 4 * (u64)len[i])
+                c = 4 * (u64)len[i];
             if (c < 4096)
                 c = 4096;
             cap[i] = c;

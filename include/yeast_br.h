@@ -34,6 +34,22 @@ extern "C" {
  */
 int yeast_broad(const void *br, size_t len, void **out, size_t *out_len, int write, size_t *segments);
 
+/*
+ * Wrap one brotli stream into a .br file: the reference's brand program (brand.c:93-314; wrap() and
+ * main()).  opt is brand's option string (brand.c:79-92: 1 2 4 8 x c s n u r b f m; NULL = ""), name
+ * the file name stored with 'f' (NULL = "filename", brand.c:308).  The stream is decoded on the GPU to
+ * get its length and check value.  *out is a malloc() buffer.  Returns 0, 1 when the stream does not
+ * decode to its end exactly (brand.c:300-304) or memory ran out, -1 when the GPU path is unavailable.
+ */
+int yeast_brand(const void *brotli, size_t len, const char *opt, const char *name, void **out, size_t *out_len);
+
+/*
+ * Merge n .br files into one without decoding them: the reference's braid program (braid.c:146-422).
+ * Files without a complete chain of reverse offsets are skipped (braid.c:392-396) and make the
+ * return value 1, as braid's exit status; otherwise 0.  *out is a malloc() buffer.
+ */
+int yeast_braid(size_t n, void const *const *br, const size_t *len, void **out, size_t *out_len);
+
 /* SHA-256 over host buffers, computed on the GPU (the reference: OpenSSL's SHA256(), broad.c:266,
    brand.c:241).  Return 0, or -1 when the GPU path is unavailable. */
 int yeast_sha256(const void *buf, size_t len, unsigned char out[32]);

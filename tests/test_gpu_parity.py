@@ -248,3 +248,42 @@ def test_br_container_reader_every_fixture():
         assert ba.sha256(msg) == hashlib.sha256(msg).digest()
     c, data = [x for x in cases if x[0]["name"] == "multi/text-12x64KiB"][0]
     assert ba.broad(data, write=False) == (0, b"", 12)
+
+
+def test_br_writer_and_merger_byte_exact():
+    # brand (brand.c:93-314) and braid (braid.c:146-422).  Expected bytes are the output of
+    # the reference's own programs on the same inputs (tools/make_br_fixtures.py); merges include files
+    # braid skips (no chain of reverse offsets) with its exit status, bare trailers and the empty merge.
+    cases = H.br_cases()
+    by = {c["name"]: d for c, d in cases}
+    meta2, cfg2 = H.packed_streams("cfg2_streams")
+
+    def td(name):
+        return open(os.path.join(H.GOLD, "testdata", name + ".compressed"), "rb").read()
+    nb = nm = 0
+    for c, data in cases:
+        m = c.get("made")
+        if not m:
+            continue
+        if "brand" in m:
+            s, opt, name = m["brand"]
+            assert ba.brand(td(s), opt, name) == (0, data), c["name"]
+            nb += 1
+        elif "braid" in m:
+            assert ba.braid([by[n] for n in m["braid"]]) == (m.get("ret", 0), data), c["name"]
+            nm += 1
+        else:
+            parts = []
+            for kind, s, opt in m["braid_brand"]:
+                rc, b = ba.brand(cfg2[s] if kind == "cfg2" else td(s), opt)
+                assert rc == 0
+                parts.append(b)
+            assert ba.braid(parts) == (0, data), c["name"]
+            nm += 1
+    assert nb > 60 and nm >= 14
+    # a stream with trailing bytes, or a damaged one, is refused as brand refuses it (brand.c:300-304)
+    assert ba.brand(td("quickfox") + b"\0")[0] == 1
+    assert ba.brand(td("quickfox")[:-3])[0] == 1
+    # what is written here reads back through the reader
+    rc, b = ba.brand(cfg2[3], "c2u")
+    assert ba.broad(b) == (0, H.oracle_yeast(cfg2[3])[3], 1)

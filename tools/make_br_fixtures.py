@@ -63,6 +63,8 @@ def td(name):
 
 
 cases = []
+made = {}     # name -> how the writer/merger tests rebuild the file: {"brand": [testdata stream, options, name]},
+              # {"braid": [case names]} or {"braid_brand": [[kind, stream, options], ...]}; "ret" = braid's exit status
 recipes = {}  # name -> (base name, "xor", pos, mask) or (base name, "cut", n): damaged copies are stored as recipes
 
 
@@ -81,14 +83,15 @@ for o in opts:
         b = brand(td(s), o, "a name" if "f" in o else None)
         singles[(s, o)] = b
         add("single/%s/%s" % (s, o or "default"), b)
+        made["single/%s/%s" % (s, o or "default")] = {"brand": [s, o, "a name" if "f" in o else None]}
 # the two streams of br-format-v3.txt:416-429
 add("spec/shortest-with-data", bytes.fromhex("ceb2cf8184060027"))
 add("spec/shortest", bytes.fromhex("ceb2cf8127"))
 # large outputs
 for s in ("alice29.txt", "zeros", "backward65536", "compressed_repeated"):
-    add("single/%s/default" % s, brand(td(s)))
-    add("single/%s/c" % s, brand(td(s), "c"))
-    add("single/%s/s" % s, brand(td(s), "s"))
+    for o_ in ("", "c", "s"):
+        add("single/%s/%s" % (s, o_ or "default"), brand(td(s), o_))
+        made["single/%s/%s" % (s, o_ or "default")] = {"brand": [s, o_, None]}
 
 # merged files (braid.c): reverse offsets everywhere, total length, XXH32 check of checks
 multis = {}
@@ -103,7 +106,41 @@ multis["text-12x64KiB"] = braid([brand(cfg2[k], ("", "c", "x4", "s")[k % 4]) for
 multis["large-mix"] = braid([brand(td("alice29.txt")), brand(td("zeros"), "c"), brand(td("backward65536"), "s"),
                              brand(td("quickfox_repeated"), "x2")])
 multis["no-length"] = braid([singles[("quickfox", "n")], singles[("x", "r")], singles[("xyzzy", "")]])
+def nm(s_, o_):
+    return "single/%s/%s" % (s_, o_ or "default")
+made["multi/three-kinds"] = {"braid": [nm("quickfox", "c2"), nm("x", "s"), nm("xyzzy", "x4f")]}
+made["multi/eight-small"] = {"braid": [nm(s, "") for s in small]}
+made["multi/eight-crc"] = {"braid": [nm(s, "c") for s in small]}
+made["multi/eight-sha"] = {"braid": [nm(s, "s") for s in small]}
+made["multi/mixed-16"] = {"braid": [nm(s, o_) for o_ in ("", "c", "s") for s in small[:5]] + [nm("x", "x1")]}
+made["multi/merged-of-merged"] = {"braid": ["multi/three-kinds", "multi/eight-small", nm("monkey", "c")]}
+made["multi/text-12x64KiB"] = {"braid_brand": [["cfg2", k, ("", "c", "x4", "s")[k % 4]] for k in range(12)]}
+made["multi/large-mix"] = {"braid_brand": [["td", "alice29.txt", ""], ["td", "zeros", "c"], ["td", "backward65536", "s"],
+                                            ["td", "quickfox_repeated", "x2"]]}
+made["multi/no-length"] = {"braid": [nm("quickfox", "n"), nm("x", "r"), nm("xyzzy", "")]}
+# files braid skips (no chain of reverse offsets, damage) among good ones, and the empty merge
+def braid_rc(files):
+    paths = []
+    for k, f in enumerate(files):
+        p = os.path.join(tmp, "c%d.br" % k)
+        open(p, "wb").write(f)
+        paths.append(p)
+    r = subprocess.run([os.path.join(REF, "braid")] + paths, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    return r.returncode, r.stdout
+byname_ = lambda n_: [c for c in cases if c[0] == n_][0][1]
+for tag, names in (("skip-no-offsets", [nm("quickfox", ""), nm("x", "n"), nm("xyzzy", "u"), nm("10x10y", "")]),
+                   ("only-skipped", [nm("x", "n")]),
+                   ("none", []),
+                   ("with-bare-trailer", [nm("quickfox", ""), "spec/shortest", nm("x", "")]),
+                   ("bare-trailers", ["spec/shortest", "spec/shortest"]),
+                   ("spec-shortest-data", ["spec/shortest-with-data", nm("x", "c1")])):
+    rc_, out_ = braid_rc([byname_(n_) for n_ in names])
+    add("braid/" + tag, out_)
+    made["braid/" + tag] = {"braid": names, "ret": rc_}
 for k, v in multis.items():
+    if "braid" in made["multi/" + k]:  # braid's exit status: 1 when it skipped a file
+        made["multi/" + k]["ret"] = braid_rc([byname_(n_) if n_ in [c[0] for c in cases] else multis[n_[6:]]
+                                               for n_ in made["multi/" + k]["braid"]])[0]
     add("multi/" + k, v)
     add("multi/" + k + "+zeros", v + bytes(7))
     add("multi/" + k + "+garbage", v + b"\x55\xaa\x01")
@@ -227,6 +264,8 @@ for name, data, rc, out in cases:
     u = undefined_in_reference(data)
     if u:
         e["reference_undefined"] = u
+    if name in made:
+        e["made"] = made[name]
     if name in recipes:
         e["base"], e["op"], e["pos"], e["mask"] = recipes[name]
     else:
