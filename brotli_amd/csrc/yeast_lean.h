@@ -21,7 +21,9 @@
  *   - literals go straight to the output region;
  *   - the second half of a code longer than its root table is looked up on the next pass;
  *   - a block switch (type code, count code, reload of the new type's table offsets) is a rare
- *     phase of its own at the head of the pass.
+ *     phase of its own at the head of the pass;
+ *   - input arrives through a four-word queue behind the 64-bit window, topped up by one 8-byte
+ *     load per pass.
  */
 #ifndef YEAST_LEAN_H
 #define YEAST_LEAN_H
@@ -88,8 +90,12 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
     u32 k1 = kcls[c.p1 & 255], k2 = kcls[c.p2 & 255];
     u64 got0 = got_of(c);
     u32 maxd = got0 > c.wsize ? c.wsize : (u32)got0;
-    /* input: the window r.w and the next two words, requested ahead of their use */
-    u32 q0 = r.nxt, q1 = 0, nq = 1; /* q0 = word r.idx of the stream, q1 the one after it */
+    /* input: the window r.w and, behind it, a queue of up to four words (a0 = word r.idx of the stream,
+       then a1, b0, b1), topped up by one 8-byte load per pass: requested beside the phase (A) lookup when
+       two words or fewer are queued, merged when that phase's wait is over */
+    u32 a0 = r.nxt, a1 = 0, b0 = 0, b1 = 0, nq = 1;
+    u64 tq = 0;    /* the request in flight */
+    u32 treq = 0;
     /* copy engine */
     const u8 *psrc = c.outp; /* the piece set up on the previous pass: fetched and stored on this one */
     u8 *pdst = c.outp;
@@ -98,31 +104,45 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
     const u8 *csrc = c.outp;
     u32 crem = 0, cD = 0; /* copy in progress: bytes left, period limit */
 
-    /* move the next word into the window (the queued words have arrived by the time this runs,
-       except after a third refill between two requests: then the word is fetched on the spot) */
+
+    /* move the next word into the window (a stream that uses up its queue inside one pass -- more than
+       64 bits beyond what the window held -- fetches on the spot and waits) */
     auto refill = [&]() {
         if (r.have <= 32) {
             if (nq == 0) {
-                q0 = gld32(r.p + r.idx);
-                nq = 1;
+                u64 t = gld64u(r.p + r.idx);
+                a0 = (u32)t;
+                a1 = (u32)(t >> 32);
+                nq = 2;
             }
-            r.w |= (u64)q0 << r.have;
+            r.w |= (u64)a0 << r.have;
             u32 add = r.rem < 32 ? r.rem : 32;
             r.have += add;
             r.rem -= add;
             if (add) {
                 r.idx++;
-                q0 = q1;
+                a0 = a1;
+                a1 = b0;
+                b0 = b1;
                 nq--;
             }
         }
     };
-    auto top_up = [&]() {
-        if (nq == 0)
-            q0 = gld32(r.p + r.idx);
-        if (nq < 2)
-            q1 = gld32(r.p + r.idx + 1);
-        nq = 2;
+    auto request = [&]() {
+        treq = nq <= 2;
+        if (treq)
+            tq = gld64u(r.p + r.idx + nq);
+    };
+    auto merge = [&]() {
+        if (treq) {
+            u32 t0 = (u32)tq, t1 = (u32)(tq >> 32);
+            a0 = nq == 0 ? t0 : a0;
+            a1 = nq == 0 ? t1 : nq == 1 ? t0 : a1;
+            b0 = nq == 1 ? t1 : nq == 2 ? t0 : b0;
+            b1 = nq == 2 ? t1 : b1;
+            nq += 2;
+            treq = 0;
+        }
     };
     auto bits_mid = [&](u32 n, bool &ok) -> u32 {
         if (n > r.have)
@@ -141,7 +161,6 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
     auto lookup = [&](bool on, u32 off, u32 root) -> u32 {
         if (on)
             refill();
-        top_up();
         u32 e = 0;
         if (on) {
             u32 peek = (u32)r.w;
@@ -204,7 +223,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
 
     /* nothing loaded above is still on its way when the loop starts (a wait placed inside the loop
        for the first pass's sake would be paid on every pass) */
-    asm volatile("" : "+v"(offI), "+v"(offL), "+v"(offD), "+v"(cur_mode), "+v"(q0));
+    asm volatile("" : "+v"(offI), "+v"(offL), "+v"(offD), "+v"(cur_mode), "+v"(a0));
 #ifdef YS_PROFILE
     u64 pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pmark = __builtin_readcyclecounter();
     u32 npass = 0;
@@ -256,7 +275,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                     load_dt(n);
             }
             st = r.rc ? (u32)ST_END : cat;
-            asm volatile("" : "+v"(offI), "+v"(cur_mode), "+v"(q0), "+v"(q1));
+            asm volatile("" : "+v"(offI), "+v"(cur_mode));
         }
 
         LMARK(0);
@@ -275,9 +294,11 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             }
             const bool on = st == ST_CMD;
             u32 e = lookup(on, offI, rootI);
+            request();
             LMARK(1);
             LWAIT();
-            asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1), "+v"(pv));
+            asm volatile("" : "+v"(e), "+v"(tq), "+v"(pv));
+            merge();
             LMARK(2);
             if (pn) {
                 if (psafe) { /* the last bytes of the output region: exact */
@@ -338,7 +359,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             u32 e = lookup(on, offL, rootL);
             LMARK(4);
             LWAIT();
-            asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1));
+            asm volatile("" : "+v"(e));
             LMARK(5);
             if (decode(on, e, rootL)) {
                 u32 sym = e >> 4;
@@ -369,7 +390,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             u32 e = lookup(on, offD, rootD);
             LMARK(7);
             LWAIT();
-            asm volatile("" : "+v"(e), "+v"(q0), "+v"(q1));
+            asm volatile("" : "+v"(e));
             LMARK(8);
             bool ok = decode(on, e, rootD);
             if (ok) {

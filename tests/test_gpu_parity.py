@@ -175,6 +175,36 @@ def test_fuzzed_streams_same_error_class_and_progress(lanes, monkeypatch):
     assert {2, 3} <= classes
 
 
+@pytest.mark.parametrize("lanes", [1, 65, 16])
+def test_damage_deep_inside_full_length_streams(lanes, monkeypatch):
+    # bit flips and cuts anywhere in whole 64 KiB streams: the failure (or the wrong but valid decode)
+    # happens thousands of commands into the loop, beside healthy streams in the same wavefront
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    rnd = random.Random(977 + lanes)
+    meta, streams = H.packed_streams("cfg2_streams")
+    cases = []
+    for t in range(768):
+        s = bytearray(streams[rnd.randrange(len(streams))])
+        kind = t % 4
+        if kind == 0:
+            s = s[:rnd.randrange(1, len(s))]
+        elif kind < 3:
+            for _ in range(kind):
+                s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+        cases.append(bytes(s))  # kind 3: left whole
+    res = ba.yeast_batch(cases, ba.CHECK_XXH64)
+    classes = {}
+    o = H.oracle()
+    for k, (s, r) in enumerate(zip(cases, res)):
+        rc, got, used, out = H.oracle_yeast(s)
+        assert (r[0], r[2], r[3]) == (rc, got, used), k
+        assert r[1] == out, k
+        if rc == 0:
+            assert r[4] == o.oracle_xxh64(out, len(out), 0), k
+        classes[rc] = classes.get(rc, 0) + 1
+    assert classes.get(0, 0) >= 192 and classes.get(2, 0) >= 100 and classes.get(3, 0) >= 100, classes
+
+
 def test_full_size_batch_properties():
     # BASELINE config 2 at full size: 65,536 streams, checked through size-independent properties
     # (per-stream rc/got/used and a check-of-checks against the fixtures' reference values)
