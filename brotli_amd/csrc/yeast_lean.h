@@ -11,8 +11,9 @@
  * phase has one table lookup and waits for memory once.
  *
  *   - bytes are moved by a small per-stream copy engine: phase (D) sets up a piece of up to 16
- *     bytes (98 % of the copies of text streams are no longer), moved by one 16-byte load and store; the next pass fetches it together with the phase (A) lookup and stores it.  Literal
- *     contexts after a copy therefore never wait.  Overlapping copies (byte-serial semantics of
+ *     bytes (98 % of the copies of text streams are no longer), moved by one 16-byte load, issued
+ *     at once, and one 16-byte store after the next pass's phase (A) wait.  Literal contexts after
+ *     a copy therefore never wait.  Overlapping copies (byte-serial semantics of
  *     yeast.c:1285-1293) go in pieces no longer than their period, the period doubling with every
  *     whole period written;
  *   - static dictionary words are copies too: the source is the table of all 121 transforms of
@@ -103,31 +104,11 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
     u32 psafe = 0; /* it lies at the very end of the output region: nothing is read or written beyond it */
     const u8 *csrc = c.outp;
     u32 crem = 0, cD = 0; /* copy in progress: bytes left, period limit */
+    u32x4 pv = {0, 0, 0, 0}; /* the piece's bytes */
 
 
     /* move the next word into the window (a stream that uses up its queue inside one pass -- more than
        64 bits beyond what the window held -- fetches on the spot and waits) */
-    auto refill = [&]() {
-        if (r.have <= 32) {
-            if (nq == 0) {
-                u64 t = gld64u(r.p + r.idx);
-                a0 = (u32)t;
-                a1 = (u32)(t >> 32);
-                nq = 2;
-            }
-            r.w |= (u64)a0 << r.have;
-            u32 add = r.rem < 32 ? r.rem : 32;
-            r.have += add;
-            r.rem -= add;
-            if (add) {
-                r.idx++;
-                a0 = a1;
-                a1 = b0;
-                b0 = b1;
-                nq--;
-            }
-        }
-    };
     auto request = [&]() {
         treq = nq <= 2;
         if (treq)
@@ -142,6 +123,31 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             b1 = nq == 2 ? t1 : b1;
             nq += 2;
             treq = 0;
+        }
+    };
+    auto refill = [&]() {
+        if (r.have <= 32) {
+            if (nq == 0) {
+                if (treq) /* the words on their way are the ones wanted */
+                    merge();
+                else {
+                    u64 t = gld64u(r.p + r.idx);
+                    a0 = (u32)t;
+                    a1 = (u32)(t >> 32);
+                    nq = 2;
+                }
+            }
+            r.w |= (u64)a0 << r.have;
+            u32 add = r.rem < 32 ? r.rem : 32;
+            r.have += add;
+            r.rem -= add;
+            if (add) {
+                r.idx++;
+                a0 = a1;
+                a1 = b0;
+                b0 = b1;
+                nq--;
+            }
         }
     };
     auto bits_mid = [&](u32 n, bool &ok) -> u32 {
@@ -234,6 +240,11 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
 #define LWAIT() do { } while (0)
 #endif
     enter(ST_CMD);
+    /* the phase (A) lookup of a pass is requested at the end of the pass before it, beside the piece
+       and the input request, so that the loop back and the head of the pass run under its latency */
+    u32 eA = lookup(st == ST_CMD, offI, rootI);
+    u32 hadA = st == ST_CMD;
+    request();
     while (st != ST_END) {
 #ifdef YS_PROFILE
         npass++;
@@ -281,20 +292,19 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
         LMARK(0);
         /* ---- (A) the piece set up on the last pass, and the insert-and-copy symbol ---- */
         {
-            u32x4 pv = {0, 0, 0, 0};
-            if (pn) {
-                if (psafe) { /* at most 8 bytes, one at a time */
-                    u64 t = 0;
-                    for (u32 b = 0; b < pn; b++)
-                        t |= (u64)gld8(psrc + b) << (8 * b);
-                    pv.x = (u32)t;
-                    pv.y = (u32)(t >> 32);
-                } else
-                    pv = gld128u(psrc);
+            if (pn && psafe) { /* at most 8 bytes, one at a time (the usual piece was requested in (D)) */
+                u64 t = 0;
+                for (u32 b = 0; b < pn; b++)
+                    t |= (u64)gld8(psrc + b) << (8 * b);
+                pv.x = (u32)t;
+                pv.y = (u32)(t >> 32);
             }
             const bool on = st == ST_CMD;
-            u32 e = lookup(on, offI, rootI);
-            request();
+            u32 e = eA;
+            if (!SIMPLE) { /* a stream that has just switched blocks could not be looked up ahead */
+                u32 late = lookup(on && !hadA, offI, rootI);
+                e = on && !hadA ? late : e;
+            }
             LMARK(1);
             LWAIT();
             asm volatile("" : "+v"(e), "+v"(tq), "+v"(pv));
@@ -466,7 +476,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                     st = ST_END;
             }
         }
-        /* ---- and the next piece of the copy in progress (fetched on the next pass) ---- */
+        /* ---- and the next piece of the copy in progress (requested now, stored on the next pass) ---- */
         if (st == ST_COPY) {
             u32 m = crem < 16 ? crem : 16;
             m = m < cD ? m : cD;
@@ -479,6 +489,8 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                 csrc += m;
             pdst = c.outp;
             pn = m;
+            if (!psafe) /* requested now, used after the next pass's first wait */
+                pv = gld128u(psrc);
             c.outp += m;
             crem -= m;
             u32 room = c.wsize - maxd;
@@ -490,6 +502,10 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
                     st = ST_END;
             }
         }
+        /* ---- ahead of the next pass: its phase (A) lookup and the input request ---- */
+        hadA = st == ST_CMD;
+        eA = lookup(hadA, offI, rootI);
+        request();
         LMARK(10);
     }
 #ifdef YS_PROFILE

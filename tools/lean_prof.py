@@ -2,6 +2,7 @@
 """Phase timing of the lean batch kernel (library built with -DYS_PROFILE, loaded through YEAST_LIB):
 lane 0 of every wavefront leaves its cycle counts in the last 128 bytes of its output region."""
 import os, sys
+os.environ["YEAST_SORT"] = "0"  # lane 0 of wavefront k must hold stream k * S: the marks are read from its output region
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
