@@ -31,6 +31,8 @@ SRC_PAD = 32
 EXPORTS = [  # every symbol include/yeast.h, include/yeast_batch.h and include/yeast_br.h declare
     "yeast", "yeast_verbosity", "yeast_batch", "yeast_batch_device", "yeast_check_device",
     "crc32c", "XXH32", "XXH64", "yeast_last_error", "yeast_device_count", "yeast_debug_table",
+    "XXH32_createState", "XXH32_freeState", "XXH32_reset", "XXH32_update", "XXH32_digest",
+    "XXH64_createState", "XXH64_freeState", "XXH64_reset", "XXH64_update", "XXH64_digest",
     "yeast_broad", "yeast_brand", "yeast_braid", "yeast_sha256", "yeast_sha256_batch",  # include/yeast_br.h
 ]
 
@@ -87,6 +89,13 @@ def lib() -> ctypes.CDLL:
         L.yeast_braid.restype = ctypes.c_int
         L.yeast_braid.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t),
                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        for bits, seed_t, out_t in ((32, ctypes.c_uint, ctypes.c_uint), (64, ctypes.c_ulonglong, ctypes.c_ulonglong)):
+            getattr(L, "XXH%d_createState" % bits).restype = ctypes.c_void_p
+            getattr(L, "XXH%d_freeState" % bits).argtypes = [ctypes.c_void_p]
+            getattr(L, "XXH%d_reset" % bits).argtypes = [ctypes.c_void_p, seed_t]
+            getattr(L, "XXH%d_update" % bits).argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+            getattr(L, "XXH%d_digest" % bits).argtypes = [ctypes.c_void_p]
+            getattr(L, "XXH%d_digest" % bits).restype = out_t
         L.yeast_sha256.restype = ctypes.c_int
         L.yeast_sha256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
         _lib = L
@@ -196,6 +205,35 @@ def braid(files: Sequence[bytes]) -> Tuple[int, bytes]:
     data = ctypes.string_at(out, n.value) if out.value and n.value else b""
     _libc.free(out)
     return rc, data
+
+
+class XXHState:
+    """The reference's streaming hash interface (xxhash.h:149-167): reset / update / digest."""
+
+    def __init__(self, bits: int = 64, seed: int = 0):
+        assert bits in (32, 64)
+        self._f = lambda name: getattr(lib(), "XXH%d_%s" % (bits, name))
+        self._s = self._f("createState")()
+        if not self._s:
+            raise MemoryError("XXH%d_createState" % bits)
+        self.reset(seed)
+
+    def reset(self, seed: int = 0):
+        self._f("reset")(self._s, seed)
+        return self
+
+    def update(self, data: bytes):
+        if self._f("update")(self._s, data, len(data)):
+            raise _err("XXH_update")
+        return self
+
+    def digest(self) -> int:
+        return self._f("digest")(self._s)
+
+    def __del__(self):
+        if getattr(self, "_s", None):
+            self._f("freeState")(self._s)
+            self._s = None
 
 
 def sha256(data: bytes) -> bytes:

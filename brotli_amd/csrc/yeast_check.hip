@@ -343,3 +343,81 @@ extern "C" int ys_launch_sha256(const u8 *p, const u64 *off, const u64 *len, uns
     hipLaunchKernelGGL(k_sha256, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, p, off, len, n, out);
     return (int)hipGetLastError();
 }
+
+/* ---- streaming XXH32 / XXH64 (xxhash.c:588-960): the accumulators live with the caller between
+   updates; an update advances them over whole stripes, the digest folds them with the buffered tail.
+   v: four accumulators in u64 slots (XXH32 uses the low halves). */
+__global__ __launch_bounds__(64) void k_xxh_update(u32 is64, u64 *v, const u8 *p, u64 nstripe)
+{
+    u32 sub = threadIdx.x;
+    if (sub >= 4)
+        return;
+    if (is64) {
+        u64 acc = v[sub];
+        const u8 *q = p + (sub << 3);
+        for (u64 i = 0; i < nstripe; i++, q += 32)
+            acc = xxh64_round(acc, ld64(q));
+        v[sub] = acc;
+    } else {
+        u32 acc = (u32)v[sub];
+        const u8 *q = p + (sub << 2);
+        for (u64 i = 0; i < nstripe; i++, q += 16)
+            acc = xxh32_round(acc, ld32(q));
+        v[sub] = acc;
+    }
+}
+
+/* XXH32_digest() xxhash.c:716-752, XXH64_digest() xxhash.c:870-934; mem: the buffered tail (memsize bytes) */
+__global__ void k_xxh_digest(u32 is64, const u64 *v, u64 total, u64 seed, const u8 *mem, u32 memsize, u64 *out)
+{
+    if (threadIdx.x)
+        return;
+    const u8 *q = mem, *end = mem + memsize;
+    if (is64) {
+        u64 h;
+        if (total >= 32) {
+            h = rol64(v[0], 1) + rol64(v[1], 7) + rol64(v[2], 12) + rol64(v[3], 18);
+            h = xxh64_merge(h, v[0]);
+            h = xxh64_merge(h, v[1]);
+            h = xxh64_merge(h, v[2]);
+            h = xxh64_merge(h, v[3]);
+        } else
+            h = seed + P64_5;
+        h += total;
+        for (; q + 8 <= end; q += 8)
+            h = rol64(h ^ xxh64_round(0, ld64(q)), 27) * P64_1 + P64_4;
+        if (q + 4 <= end) {
+            h = rol64(h ^ (u64)ld32(q) * P64_1, 23) * P64_2 + P64_3;
+            q += 4;
+        }
+        for (; q < end; q++)
+            h = rol64(h ^ (u64)ld8(q) * P64_5, 11) * P64_1;
+        h ^= h >> 33; h *= P64_2; h ^= h >> 29; h *= P64_3; h ^= h >> 32;
+        *out = h;
+    } else {
+        u32 h;
+        if (total >= 16)
+            h = rol32((u32)v[0], 1) + rol32((u32)v[1], 7) + rol32((u32)v[2], 12) + rol32((u32)v[3], 18);
+        else
+            h = (u32)seed + P32_5;
+        h += (u32)total;
+        for (; q + 4 <= end; q += 4)
+            h = rol32(h + ld32(q) * P32_3, 17) * P32_4;
+        for (; q < end; q++)
+            h = rol32(h + ld8(q) * P32_5, 11) * P32_1;
+        h ^= h >> 15; h *= P32_2; h ^= h >> 13; h *= P32_3; h ^= h >> 16;
+        *out = h;
+    }
+}
+
+extern "C" int ys_launch_xxh_update(unsigned is64, u64 *v, const u8 *p, u64 nstripe, void *stream)
+{
+    hipLaunchKernelGGL(k_xxh_update, dim3(1), dim3(64), 0, (hipStream_t)stream, is64, v, p, nstripe);
+    return (int)hipGetLastError();
+}
+extern "C" int ys_launch_xxh_digest(unsigned is64, const u64 *v, u64 total, u64 seed, const u8 *mem, unsigned memsize,
+                                    u64 *out, void *stream)
+{
+    hipLaunchKernelGGL(k_xxh_digest, dim3(1), dim3(64), 0, (hipStream_t)stream, is64, v, total, seed, mem, memsize, out);
+    return (int)hipGetLastError();
+}

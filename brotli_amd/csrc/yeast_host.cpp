@@ -35,6 +35,9 @@ int ysw_launch(const ys_params *p, unsigned slot_entries, unsigned rootcaps, uns
 int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec, unsigned n, unsigned kind, u64 seed,
                     void *stream);
 int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed, u64 *out, void *stream);
+int ys_launch_xxh_update(unsigned is64, u64 *v, const u8 *p, u64 nstripe, void *stream);
+int ys_launch_xxh_digest(unsigned is64, const u64 *v, u64 total, u64 seed, const u8 *mem, unsigned memsize, u64 *out,
+                         void *stream);
 int ys_launch_sha256(const u8 *p, const u64 *off, const u64 *len, unsigned n, u8 *out, void *stream);
 int yeast_verbosity = 0;
 }
@@ -683,4 +686,143 @@ extern "C" unsigned int XXH32(const void *input, size_t len, unsigned int seed)
 extern "C" unsigned long long XXH64(const void *input, size_t len, unsigned long long seed)
 {
     return host_check(input, len, YEAST_CHECK_XXH64, seed);
+}
+
+/* ---- streaming XXH32 / XXH64: xxhash.h:139-167, xxhash.c:588-960 ------------------------------
+
+   The state is the caller's (same sizes as the reference's opaque types: 6 and 11 long longs); it holds
+   the four accumulators, the bytes of an unfinished stripe and the totals.  Bytes are only moved on the
+   host; the accumulators are advanced and the digest is folded on the GPU. */
+struct XxhState32 { /* 48 bytes */
+    u64 total;
+    u32 seed, v[4];
+    u8 mem[16];
+    u32 memsize;
+};
+struct XxhState64 { /* 88 bytes */
+    u64 total, seed, v[4];
+    u8 mem[32];
+    u32 memsize, pad;
+};
+static_assert(sizeof(XxhState32) == sizeof(XXH32_state_t) && sizeof(XxhState64) == sizeof(XXH64_state_t), "streaming state layout");
+
+extern "C" XXH32_state_t *XXH32_createState(void) { return (XXH32_state_t *)malloc(sizeof(XxhState32)); }
+extern "C" XXH64_state_t *XXH64_createState(void) { return (XXH64_state_t *)malloc(sizeof(XxhState64)); }
+extern "C" int XXH32_freeState(XXH32_state_t *s) { free(s); return 0; }
+extern "C" int XXH64_freeState(XXH64_state_t *s) { free(s); return 0; }
+
+extern "C" int XXH32_reset(XXH32_state_t *sp, unsigned seed) /* xxhash.c:588-599 */
+{
+    XxhState32 *s = (XxhState32 *)sp;
+    s->seed = seed;
+    s->v[0] = seed + 2654435761u + 2246822519u;
+    s->v[1] = seed + 2246822519u;
+    s->v[2] = seed;
+    s->v[3] = seed - 2654435761u;
+    s->total = 0;
+    s->memsize = 0;
+    return 0;
+}
+extern "C" int XXH64_reset(XXH64_state_t *sp, unsigned long long seed) /* xxhash.c:601-612 */
+{
+    XxhState64 *s = (XxhState64 *)sp;
+    s->seed = seed;
+    s->v[0] = seed + 11400714785074694791ull + 14029467366897019727ull;
+    s->v[1] = seed + 14029467366897019727ull;
+    s->v[2] = seed;
+    s->v[3] = seed - 11400714785074694791ull;
+    s->total = 0;
+    s->memsize = 0;
+    return 0;
+}
+
+/* advance acc[4] over the whole stripes of mem[0..memsize) ++ in[0..len); the rest goes back to mem */
+static int xxh_update(unsigned is64, u64 *acc, u8 *mem, u32 *memsize, const void *in, size_t len)
+{
+    const size_t stripe = is64 ? 32 : 16;
+    if (*memsize + len < stripe) { /* xxhash.c:627-632, 781-786 */
+        if (len)
+            memcpy(mem + *memsize, in, len);
+        *memsize += (u32)len;
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    Device *d;
+    if (device_get(&d))
+        return 1;
+    size_t have = *memsize + len, nstripe = have / stripe, rest = have - nstripe * stripe;
+    size_t data_at = 64;
+    if (grow(d->scratch, data_at + have + 64))
+        return 1;
+    u8 *base = (u8 *)d->scratch.p;
+    HIPCK(hipMemcpyAsync(base, acc, 32, hipMemcpyHostToDevice, nullptr));
+    if (*memsize)
+        HIPCK(hipMemcpyAsync(base + data_at, mem, *memsize, hipMemcpyHostToDevice, nullptr));
+    HIPCK(hipMemcpyAsync(base + data_at + *memsize, in, len, hipMemcpyHostToDevice, nullptr));
+    int e = ys_launch_xxh_update(is64, (u64 *)base, base + data_at, nstripe, nullptr);
+    if (e)
+        return fail("xxh update launch", (hipError_t)e), 1;
+    HIPCK(hipMemcpy(acc, base, 32, hipMemcpyDeviceToHost));
+    if (rest)
+        memcpy(mem, (const u8 *)in + (len - rest), rest);
+    *memsize = (u32)rest;
+    return 0;
+}
+static int xxh_digest(unsigned is64, const u64 *acc, u64 total, u64 seed, const u8 *mem, u32 memsize, u64 *out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Device *d;
+    if (device_get(&d) || grow(d->scratch, 256))
+        return 1;
+    u8 *base = (u8 *)d->scratch.p;
+    HIPCK(hipMemcpyAsync(base, acc, 32, hipMemcpyHostToDevice, nullptr));
+    HIPCK(hipMemcpyAsync(base + 64, mem, 32, hipMemcpyHostToDevice, nullptr));
+    int e = ys_launch_xxh_digest(is64, (const u64 *)base, total, seed, base + 64, memsize, (u64 *)(base + 128), nullptr);
+    if (e)
+        return fail("xxh digest launch", (hipError_t)e), 1;
+    HIPCK(hipMemcpy(out, base + 128, 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int XXH32_update(XXH32_state_t *sp, const void *input, size_t len) /* xxhash.c:614-702 */
+{
+    XxhState32 *s = (XxhState32 *)sp;
+    if (input == nullptr)
+        return 1;
+    s->total += len;
+    u64 acc[4] = {s->v[0], s->v[1], s->v[2], s->v[3]};
+    int e = xxh_update(0, acc, s->mem, &s->memsize, input, len);
+    for (int k = 0; k < 4; k++)
+        s->v[k] = (u32)acc[k];
+    return e ? 1 : 0;
+}
+extern "C" int XXH64_update(XXH64_state_t *sp, const void *input, size_t len) /* xxhash.c:768-856 */
+{
+    XxhState64 *s = (XxhState64 *)sp;
+    if (input == nullptr)
+        return 1;
+    s->total += len;
+    return xxh_update(1, s->v, s->mem, &s->memsize, input, len) ? 1 : 0;
+}
+extern "C" unsigned int XXH32_digest(const XXH32_state_t *sp) /* xxhash.c:706-765 */
+{
+    const XxhState32 *s = (const XxhState32 *)sp;
+    u64 acc[4] = {s->v[0], s->v[1], s->v[2], s->v[3]}, out = 0;
+    u8 mem[32] = {0};
+    memcpy(mem, s->mem, 16);
+    if (xxh_digest(0, acc, s->total, s->seed, mem, s->memsize, &out)) {
+        fprintf(stderr, "libyeast_mi355x: XXH32_digest could not run on the GPU (%s)\n", t_err);
+        abort();
+    }
+    return (unsigned int)out;
+}
+extern "C" unsigned long long XXH64_digest(const XXH64_state_t *sp) /* xxhash.c:860-940 */
+{
+    const XxhState64 *s = (const XxhState64 *)sp;
+    u64 out = 0;
+    if (xxh_digest(1, s->v, s->total, s->seed, s->mem, s->memsize, &out)) {
+        fprintf(stderr, "libyeast_mi355x: XXH64_digest could not run on the GPU (%s)\n", t_err);
+        abort();
+    }
+    return out;
 }

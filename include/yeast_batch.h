@@ -88,6 +88,27 @@ uint32_t crc32c(uint32_t crc, void const *buf, size_t len);
 unsigned int XXH32(const void *input, size_t len, unsigned int seed);
 unsigned long long XXH64(const void *input, size_t len, unsigned long long seed);
 
+/*
+ * The streaming forms of the two hashes (xxhash.h:139-167, xxhash.c:588-960), which broad.c:31-62,121-122
+ * and braid.c:205-242,345 use for header checks and the check of checks; crc32c() above is already
+ * chainable through its first argument (crc32c.c:258).  Same names, argument meaning and return
+ * values (0 = XXH_OK, 1 = XXH_ERROR); the state types have the reference's sizes.  The state holds
+ * the accumulators and the bytes of an unfinished stripe; every update that completes a stripe and
+ * every digest is one small launch.
+ */
+typedef struct { long long ll[6]; } XXH32_state_t;
+typedef struct { long long ll[11]; } XXH64_state_t;
+XXH32_state_t *XXH32_createState(void);
+int XXH32_freeState(XXH32_state_t *state);
+XXH64_state_t *XXH64_createState(void);
+int XXH64_freeState(XXH64_state_t *state);
+int XXH32_reset(XXH32_state_t *state, unsigned seed);
+int XXH32_update(XXH32_state_t *state, const void *input, size_t length);
+unsigned int XXH32_digest(const XXH32_state_t *state);
+int XXH64_reset(XXH64_state_t *state, unsigned long long seed);
+int XXH64_update(XXH64_state_t *state, const void *input, size_t length);
+unsigned long long XXH64_digest(const XXH64_state_t *state);
+
 /* Diagnostics. */
 const char *yeast_last_error(void);   /* thread-local text of the last failure, "" if none */
 int yeast_device_count(void);         /* HIP devices visible, <= 0 if none */

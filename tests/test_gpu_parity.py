@@ -317,3 +317,37 @@ def test_br_writer_and_merger_byte_exact():
     # what is written here reads back through the reader
     rc, b = ba.brand(cfg2[3], "c2u")
     assert ba.broad(b) == (0, H.oracle_yeast(cfg2[3])[3], 1)
+
+
+def test_streaming_hashes_any_chunking():
+    # XXH32/XXH64 reset/update/digest (xxhash.c:588-960) and chained crc32c (crc32c.c:258):
+    # whatever the chunking, the digest is the one-shot value of the restatement; digests in mid-stream
+    # do not disturb the state; the check of checks of a merged file is reproduced the way braid builds it
+    o = H.oracle()
+    rnd = random.Random(5)
+    alice = open(os.path.join(H.GOLD, "testdata", "alice29.txt"), "rb").read()
+    for trial in range(24):
+        data = alice[rnd.randrange(2000):][:rnd.choice([0, 1, 15, 16, 17, 31, 32, 33, 100, 4096, 50001])]
+        seed = rnd.choice([0, 1, 0x9E3779B1])
+        s32, s64, crc, at = ba.XXHState(32, seed), ba.XXHState(64, seed), 0, 0
+        while at < len(data):
+            n = rnd.choice([0, 1, 3, 15, 16, 17, 31, 32, 33, 64, 1000, 7777])
+            piece = data[at:at + n]
+            s32.update(piece)
+            s64.update(piece)
+            crc = ba.crc32c(piece, crc)
+            at += len(piece)
+            if rnd.random() < 0.3:
+                assert s32.digest() == o.oracle_xxh32(data[:at], at, seed)
+                assert s64.digest() == o.oracle_xxh64(data[:at], at, seed)
+        assert s32.digest() == o.oracle_xxh32(data, len(data), seed), (trial, len(data))
+        assert s64.digest() == o.oracle_xxh64(data, len(data), seed), (trial, len(data))
+        assert crc == o.oracle_crc32c(0, data, len(data))
+    # the XXH32 check of checks in the trailer of a merged file, built as braid builds it (braid.c:337,414):
+    # one update per segment with that segment's stored check value (here XXH64, eight bytes each)
+    c, data = [x for x in H.br_cases() if x[0]["name"] == "multi/eight-small"][0]
+    st = ba.XXHState(32, 0)
+    for name in c["made"]["braid"]:
+        plain = open(os.path.join(H.GOLD, "testdata", name.split("/")[1]), "rb").read()
+        st.update(o.oracle_xxh64(plain, len(plain), 0).to_bytes(8, "little"))
+    assert st.digest() == int.from_bytes(data[-5:-1], "little")
