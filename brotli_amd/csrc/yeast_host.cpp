@@ -323,9 +323,12 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     const bool flat = lanes == 1;
     /* one stream per lane: half-filled wavefronts (two per SIMD, the default), full ones (0) or
        quarter-filled ones (2) */
-    const int half = flat ? env_int("YEAST_HALF", 1) : 0;
+    /* up to 65,536 streams per 256 CUs fit half-filled wavefronts, two per SIMD (one round); twice
+       that and more run in full wavefronts, two per SIMD (116 ms against 127 ms at 131,072 streams) */
+    const bool many = n >= (size_t)d.cus * 512;
+    const int half = flat ? env_int("YEAST_HALF", many ? 0 : 1) : 0;
     unsigned per_block = 256u / (unsigned)lanes / (half == 2 ? 4u : half ? 2u : 1u);
-    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : half ? 2 : 1) : 4);
+    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : 2) : 4);
     size_t want_blocks = (n + per_block - 1) / per_block;
     size_t max_blocks = (size_t)d.cus * blocks_per_cu;
     unsigned blocks = (unsigned)(want_blocks < max_blocks ? want_blocks : max_blocks);
