@@ -123,3 +123,36 @@ def br_cases():
             return bytes(b[:c["pos"]])
         return blob[c["off"]:c["off"] + c["len"]]
     return [(c, data_of(c)) for c in meta["cases"]]
+
+
+# Streams of this repo's own, written in the reference's brogen notation (tools/brogen.py): complex
+# prefix codes, which none of the reference's .gen files describes with the `c` command.  Each is
+# (text, expected output or None for "only compare decoders").
+_LEAD = """w last m 4
+types 1 types 1 types 1
+b 2 0 b 4 0
+b 2 0
+types 1 types 1
+"""
+_TAIL = """s 1 1 10 160    # insert 4, copy 2
+s 2 1 6 0
+p 1 160
+"""
+OWN_GEN = {
+    "complex-runs": (_LEAD + "c 0 3 10 3 11 3 12 3 13 4 65 4 66 4 67 4 68 5 200 5 201 5 202 5 203 5 204 5 205 5 206 5 207\n"
+                     + _TAIL + "p 0 65 10 207 13\n", bytes([65, 10, 207, 13])),
+    "complex-every-length": (_LEAD + "c 0 " + " ".join("%d %d" % (min(k + 1, 15), 16 * k) for k in range(16)) + "\n"
+                             + _TAIL + "p 0 0 240 224 16\n", bytes([0, 240, 224, 16])),
+    "complex-two-symbols": (_LEAD + "c 0 1 97 1 98\n" + _TAIL + "p 0 98 97 97 98\n", b"baab"),
+    "complex-long-repeat": (_LEAD + "c 0 " + " ".join("7 %d" % k for k in range(100, 228)) + "\n"
+                            + _TAIL + "p 0 100 227 163 101\n", bytes([100, 227, 163, 101])),
+    "complex-cut-short": (_LEAD + "c 0 3 10 3 11 3 12 3 13 4 65 4 66 4 67 4 68 5 200 5 201 5 202 5 203 5 204 5 205 5 206 5 207\n"
+                          + _TAIL + "p 0 65 10\n", None),
+}
+
+
+def own_streams():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from brogen import brogen
+    return {k: (brogen(text), want) for k, (text, want) in OWN_GEN.items()}

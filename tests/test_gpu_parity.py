@@ -351,3 +351,18 @@ def test_streaming_hashes_any_chunking():
         plain = open(os.path.join(H.GOLD, "testdata", name.split("/")[1]), "rb").read()
         st.update(o.oracle_xxh64(plain, len(plain), 0).to_bytes(8, "little"))
     assert st.digest() == int.from_bytes(data[-5:-1], "little")
+
+
+@pytest.mark.parametrize("lanes", KERNELS)
+def test_streams_written_in_the_brogen_notation(lanes, monkeypatch):
+    # complex prefix codes described with tools/brogen.py's `c` command (every length 1..15, long
+    # repeats of a length and of zero, a two-symbol code, a stream cut short inside its literals)
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    own = H.own_streams()
+    names = sorted(own)
+    res = ba.yeast_batch([own[k][0] for k in names])
+    for k, r in zip(names, res):
+        rc, got, used, out = H.oracle_yeast(own[k][0])
+        assert (r[0], r[2], r[3], r[1]) == (rc, got, used, out), k
+        if own[k][1] is not None:
+            assert (r[0], r[1]) == (0, own[k][1]), k
