@@ -366,3 +366,41 @@ def test_streams_written_in_the_brogen_notation(lanes, monkeypatch):
         assert (r[0], r[2], r[3], r[1]) == (rc, got, used, out), k
         if own[k][1] is not None:
             assert (r[0], r[1]) == (0, own[k][1]), k
+
+
+def test_reference_br_programs_linked_against_the_drop_in(tmp_path):
+    # the reference's own broad.c, brand.c and braid.c, compiled unmodified and linked against
+    # libyeast_mi355x.so for yeast(), crc32c(), XXH32(), XXH64() and the streaming XXH calls
+    # (oracle/Makefile `brdropin`; SHA-256 from the image's libcrypto, as in the reference)
+    ref = os.path.join(H.ROOT, "oracle", "_ref")
+    if not all(os.path.exists(os.path.join(ref, b)) for b in ("broad_dropin", "brand_dropin", "braid_dropin")):
+        pytest.skip("drop-in .br binaries were not built")
+    cases = H.br_cases()
+    by = {c["name"]: (c, d) for c, d in cases}
+
+    def td(name):
+        return open(os.path.join(H.GOLD, "testdata", name + ".compressed"), "rb").read()
+    # brand: the same bytes as the fixtures (which the reference's own build wrote)
+    for name in ("single/quickfox/c2", "single/x/s", "single/xyzzy/x4f", "single/alice29.txt/default"):
+        c, want = by[name]
+        s, opt, fname = c["made"]["brand"]
+        args = [os.path.join(ref, "brand_dropin")] + ([opt] if opt or fname else []) + ([fname] if fname else [])
+        p = subprocess.run(args, input=td(s), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.stdout == want, name
+    # braid over files on disk
+    parts = []
+    for k, name in enumerate(by["multi/three-kinds"][0]["made"]["braid"]):
+        f = tmp_path / ("p%d.br" % k)
+        f.write_bytes(by[name][1])
+        parts.append(str(f))
+    p = subprocess.run([os.path.join(ref, "braid_dropin")] + parts, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.stdout == by["multi/three-kinds"][1]
+    # broad: data written and the verdict (it prints "broad() error: ..." and nothing else on failure)
+    for name in ("multi/three-kinds", "multi/mixed-16", "multi/large-mix", "stream/trailer-kind-3", "spec/shortest"):
+        c, data = by[name]
+        p = subprocess.run([os.path.join(ref, "broad_dropin")], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.stderr == b"" and len(p.stdout) == c["out_len"], (name, p.stderr[-200:])
+        assert "%016x" % ba.xxh64(p.stdout) == c["out_xxh64"], name
+    c, data = by["damage/three-kinds/60^ff"] if "damage/three-kinds/60^ff" in by else by["cut/three-kinds/70"]
+    p = subprocess.run([os.path.join(ref, "broad_dropin")], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert (p.stderr != b"") == (c["rc"] != 0)
