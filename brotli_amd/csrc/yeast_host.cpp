@@ -128,6 +128,7 @@ struct Device {
     u32 *d_xbase = nullptr;  /* [121][21] offsets into it */
     int cus = 256;
     Buf src, dst, soff, doff, rec, ws, ws_big, ctr, scratch;
+    Buf pin; /* pinned host staging for the outputs of a large host-pointer batch */
 };
 
 static Device g_dev[64];
@@ -144,6 +145,20 @@ static int grow(Buf &b, size_t need)
     b.cap = 0;
     size_t cap = need + need / 4 + 4096;
     HIPCK(hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return 0;
+}
+
+static int grow_pinned(Buf &b, size_t need)
+{
+    if (need <= b.cap && b.p)
+        return 0;
+    if (b.p)
+        (void)hipHostFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t cap = need + need / 4 + 4096;
+    HIPCK(hipHostMalloc(&b.p, cap, hipHostMallocDefault));
     b.cap = cap;
     return 0;
 }
@@ -537,6 +552,14 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
         HIPCK(hipMemcpyAsync(r.data(), d.rec.p, m * sizeof(ys_record), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
 
+        /* many outputs: the whole output arena comes back in one copy through pinned memory and is
+           cut up on the host (one copy per stream costs more in calls than in bytes) */
+        const u8 *bulk = nullptr;
+        if (!cmp && out && m >= 64 && dtot <= ((u64)8 << 30) && grow_pinned(d.pin, dtot) == 0) {
+            HIPCK(hipMemcpyAsync(d.pin.p, d.dst.p, dtot, hipMemcpyDeviceToHost, st));
+            HIPCK(hipStreamSynchronize(st));
+            bulk = (const u8 *)d.pin.p;
+        }
         std::vector<size_t> again;
         for (size_t k = 0; k < m; k++) {
             size_t i = todo[k];
@@ -557,7 +580,10 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
                 out[i] = malloc(r[k].got);
                 if (!out[i])
                     return 1;
-                HIPCK(hipMemcpyAsync(out[i], (u8 *)d.dst.p + doff[k], r[k].got, hipMemcpyDeviceToHost, st));
+                if (bulk)
+                    memcpy(out[i], bulk + doff[k], r[k].got);
+                else
+                    HIPCK(hipMemcpyAsync(out[i], (u8 *)d.dst.p + doff[k], r[k].got, hipMemcpyDeviceToHost, st));
             }
         }
         HIPCK(hipStreamSynchronize(st));
