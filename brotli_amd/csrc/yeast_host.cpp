@@ -1,12 +1,13 @@
 /*
- * yeast_host.cpp -- host side of libyeast_mi355x.so: the C-ABI of
- * include/yeast.h and include/yeast_batch.h on top of the HIP kernels in
- * yeast_kernels.hip.  No decode logic lives here: the host only stages
- * buffers, sizes output regions, launches, and retries a stream whose output
- * region or table arena turned out too small.
+ * yeast_host.cpp -- host side of libyeast_mi355x.so: the C-ABI of include/yeast.h and
+ * include/yeast_batch.h (and the SHA-256 calls of include/yeast_br.h) on top of the HIP kernels of
+ * yeast_lane.hip (one stream per lane), yeast_wave.hip (one wavefront per stream), yeast_decode.hip
+ * (cooperative groups, compare mode) and yeast_check.hip.  No decode or check arithmetic lives here:
+ * the host stages buffers, sizes output regions, picks the kernel for the batch size, launches, and
+ * retries a stream whose output region or table arena turned out too small.
  *
- * Reference counterparts: yeast() yeast.c:1353-1400 (contract yeast.h:7-25);
- * crc32c() crc32c.c:258; XXH32()/XXH64() xxhash.c:365,505.
+ * Reference counterparts: yeast() yeast.c:1353-1400 (contract yeast.h:7-25); crc32c() crc32c.c:258;
+ * XXH32()/XXH64() xxhash.c:365,505 and their streaming forms xxhash.c:588-960.
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>
