@@ -28,6 +28,12 @@ DEV u32x4 gld128u(const void *p) /* unaligned */
     typedef u32x4 __attribute__((aligned(1))) u32x4u;
     return *(const GAS u32x4u *)p;
 }
+/* the same with the streaming hint: the line is not kept in L2 for this access */
+DEV u32x4 gld128u_nt(const void *p)
+{
+    typedef u32x4 __attribute__((aligned(1))) u32x4u;
+    return __builtin_nontemporal_load((const GAS u32x4u *)p);
+}
 DEV void gst128u(void *p, u32x4 v)
 {
     typedef u32x4 __attribute__((aligned(1))) u32x4u;

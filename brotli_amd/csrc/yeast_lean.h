@@ -490,7 +490,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
             pdst = c.outp;
             pn = m;
             if (!psafe) /* requested now, used after the next pass's first wait */
-                pv = gld128u(psrc);
+                pv = gld128u_nt(psrc); /* read once, far back in the output: not worth a place in L2 */
             c.outp += m;
             crem -= m;
             u32 room = c.wsize - maxd;
