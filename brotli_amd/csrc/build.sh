@@ -26,5 +26,5 @@ wait $P3
 wait $P4
 wait $P5
 wait $P6
-$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT/libyeast_mi355x.so" yeast_decode.o yeast_wave.o yeast_lane.o yeast_check.o yeast_host.o yeast_br.o yeast_data.o
+$HIPCC -shared -fPIC -pthread --offload-arch=gfx950 -o "$OUT/libyeast_mi355x.so" yeast_decode.o yeast_wave.o yeast_lane.o yeast_check.o yeast_host.o yeast_br.o yeast_data.o
 echo "built $OUT/libyeast_mi355x.so"

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "yeast_common.h"
@@ -129,7 +131,8 @@ struct Device {
     u32 *d_xbase = nullptr;  /* [121][21] offsets into it */
     int cus = 256;
     Buf src, dst, soff, doff, rec, ws, ws_big, ctr, scratch;
-    Buf pin; /* pinned host staging for the outputs of a large host-pointer batch */
+    Buf pin;    /* pinned host staging for the outputs of a large host-pointer batch */
+    Buf pin_in; /* and for its packed inputs */
 };
 
 static Device g_dev[64];
@@ -486,6 +489,24 @@ static u64 first_mlen_guess(const u8 *s, size_t len)
 
 static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+/* Packing the inputs and cutting up the outputs of a large host-pointer batch is plain memcpy: a few
+   host threads (YEAST_HOST_THREADS, default 8) share it, fn(first, last) each over its range. */
+template <class F> static void host_parallel(size_t n, u64 bytes, F fn)
+{
+    unsigned t = (unsigned)env_int("YEAST_HOST_THREADS", 8), hw = std::thread::hardware_concurrency();
+    if (hw && t > hw)
+        t = hw;
+    if (bytes < ((u64)8 << 20) || n < 64 || t < 2) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < t; k++)
+        th.emplace_back(fn, n * k / t, n * (k + 1) / t);
+    for (std::thread &x : th)
+        x.join();
+}
+
 /* Decode n host streams; fills rec[] and, for cmp == 0, out[i] (malloc'd).
    expected/have: compare mode inputs (cmp != 0, n == 1 in practice). */
 static int run_host_batch(size_t n, void const *const *src, const size_t *len, std::vector<ys_record> &rec,
@@ -536,12 +557,22 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
         if (grow(d.src, stot + YS_SRC_PAD + 64) || grow(d.dst, dtot + 64) || grow(d.soff, (m + 1) * 8) ||
             grow(d.doff, (m + 1) * 8) || grow(d.rec, m * sizeof(ys_record)))
             return -1;
-        /* stage the inputs through one pinned-size host vector */
-        std::vector<u8> pack(stot + YS_SRC_PAD, 0);
-        for (size_t k = 0; k < m; k++)
-            if (len[todo[k]])
-                memcpy(pack.data() + soff[k], src[todo[k]], len[todo[k]]);
-        HIPCK(hipMemcpyAsync(d.src.p, pack.data(), pack.size(), hipMemcpyHostToDevice, st));
+        /* the inputs go over back to back: packed into pinned memory when there is much of them */
+        std::vector<u8> pack_small;
+        u8 *pack;
+        if (stot >= ((u64)8 << 20) && grow_pinned(d.pin_in, stot + YS_SRC_PAD) == 0)
+            pack = (u8 *)d.pin_in.p;
+        else {
+            pack_small.resize(stot + YS_SRC_PAD);
+            pack = pack_small.data();
+        }
+        host_parallel(m, stot, [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; k++)
+                if (len[todo[k]])
+                    memcpy(pack + soff[k], src[todo[k]], len[todo[k]]);
+        });
+        memset(pack + stot, 0, YS_SRC_PAD);
+        HIPCK(hipMemcpyAsync(d.src.p, pack, stot + YS_SRC_PAD, hipMemcpyHostToDevice, st));
         HIPCK(hipMemcpyAsync(d.soff.p, soff.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
         HIPCK(hipMemcpyAsync(d.doff.p, doff.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
         if (cmp && have)
@@ -577,15 +608,30 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
                 return -1;
             }
             rec[i] = r[k];
-            if (!cmp && out && r[k].got) {
+            if (!cmp && out && r[k].got && !bulk) {
                 out[i] = malloc(r[k].got);
                 if (!out[i])
                     return 1;
-                if (bulk)
-                    memcpy(out[i], bulk + doff[k], r[k].got);
-                else
-                    HIPCK(hipMemcpyAsync(out[i], (u8 *)d.dst.p + doff[k], r[k].got, hipMemcpyDeviceToHost, st));
+                HIPCK(hipMemcpyAsync(out[i], (u8 *)d.dst.p + doff[k], r[k].got, hipMemcpyDeviceToHost, st));
             }
+        }
+        if (bulk) { /* one malloc'd buffer per stream, as the single call returns it */
+            std::atomic<int> nomem{0};
+            host_parallel(m, dtot, [&](size_t k0, size_t k1) {
+                for (size_t k = k0; k < k1; k++) {
+                    if (r[k].rc == YS_CAPACITY || !r[k].got)
+                        continue;
+                    void *o = malloc(r[k].got);
+                    if (!o) {
+                        nomem = 1;
+                        return;
+                    }
+                    memcpy(o, bulk + doff[k], r[k].got);
+                    out[todo[k]] = o;
+                }
+            });
+            if (nomem)
+                return 1;
         }
         HIPCK(hipStreamSynchronize(st));
         todo.swap(again);
