@@ -19,6 +19,7 @@
 #include <string.h>
 #include <map>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/yeast.h"
@@ -359,7 +360,12 @@ extern "C" int yeast_broad(const void *br, size_t len, void **out, size_t *out_l
 
     /* ---- the reference's walk: broad.c:154-341 ---- */
     uint8_t *written = nullptr;
-    size_t nwritten = 0, cap = 0, nseg = 0;
+    size_t nwritten = 0, nseg = 0;
+    struct Piece {
+        void *data;
+        size_t got;
+    };
+    std::vector<Piece> pieces; /* the verified segments in order: put together when the walk is over */
     std::vector<uint8_t> checks; /* the stored check values in order: broad.c:294 */
     void *un = nullptr;
     int code = 0;
@@ -420,16 +426,9 @@ extern "C" int yeast_broad(const void *br, size_t len, void **out, size_t *out_l
             }
             checks.insert(checks.end(), b + c.next - n, b + c.next);
             if (write && d.got) { /* :297-301 */
-                if (nwritten + d.got > cap) {
-                    size_t want = (nwritten + d.got) * 2 + 64;
-                    uint8_t *w2 = (uint8_t *)realloc(written, want);
-                    if (!w2)
-                        throw Fail{1};
-                    written = w2;
-                    cap = want;
-                }
-                memcpy(written + nwritten, un, d.got);
+                pieces.push_back(Piece{un, d.got});
                 nwritten += d.got;
+                un = nullptr;
             }
             free(un);
             un = nullptr;
@@ -459,10 +458,37 @@ extern "C" int yeast_broad(const void *br, size_t len, void **out, size_t *out_l
     }
     free(un);
     drop_ready();
-    if (out && write && nwritten)
-        *out = written;
-    else
-        free(written);
+    /* what broad() has written by now, as one buffer: allocated once at its final size and filled by a few
+       host threads (most of the cost is the first touch of its pages) */
+    if (out && write && nwritten) {
+        written = (uint8_t *)malloc(nwritten);
+        if (written) {
+            std::vector<size_t> at(pieces.size() + 1, 0);
+            for (size_t k = 0; k < pieces.size(); k++)
+                at[k + 1] = at[k] + pieces[k].got;
+            auto fill = [&](size_t k0, size_t k1) {
+                for (size_t k = k0; k < k1; k++)
+                    memcpy(written + at[k], pieces[k].data, pieces[k].got);
+            };
+            unsigned t = std::thread::hardware_concurrency();
+            t = t > 8 ? 8 : t;
+            if (nwritten < ((size_t)8 << 20) || pieces.size() < 64 || t < 2)
+                fill(0, pieces.size());
+            else {
+                std::vector<std::thread> th;
+                for (unsigned k = 0; k < t; k++)
+                    th.emplace_back(fill, pieces.size() * k / t, pieces.size() * (k + 1) / t);
+                for (std::thread &x : th)
+                    x.join();
+            }
+            *out = written;
+        } else {
+            code = 1;
+            nwritten = 0;
+        }
+    }
+    for (Piece &q : pieces)
+        free(q.data);
     if (out_len)
         *out_len = write ? nwritten : 0;
     if (segments)
