@@ -30,7 +30,7 @@ SRC_PAD = 32
 
 EXPORTS = [  # every symbol include/yeast.h, include/yeast_batch.h and include/yeast_br.h declare
     "yeast", "yeast_verbosity", "yeast_batch", "yeast_batch_device", "yeast_check_device",
-    "crc32c", "XXH32", "XXH64", "yeast_last_error", "yeast_device_count", "yeast_debug_table",
+    "crc32c", "XXH32", "XXH64", "yeast_last_error", "yeast_device_count", "yeast_debug_table", "yeast_trim",
     "XXH32_createState", "XXH32_freeState", "XXH32_reset", "XXH32_update", "XXH32_digest",
     "XXH64_createState", "XXH64_freeState", "XXH64_reset", "XXH64_update", "XXH64_digest",
     "yeast_broad", "yeast_brand", "yeast_braid", "yeast_sha256", "yeast_sha256_batch",  # include/yeast_br.h
@@ -242,6 +242,12 @@ def sha256(data: bytes) -> bytes:
     if lib().yeast_sha256(data, len(data), out):
         raise _err("yeast_sha256")
     return out.raw
+
+
+def trim() -> None:
+    """yeast_trim(): give back the buffers the library holds on the current device between calls."""
+    if lib().yeast_trim():
+        raise _err("yeast_trim")
 
 
 def debug_table(which: int) -> bytes:

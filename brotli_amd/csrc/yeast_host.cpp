@@ -233,6 +233,30 @@ static int device_get(Device **out)
     return 0;
 }
 
+extern "C" int yeast_trim(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int id = 0;
+    HIPCK(hipGetDevice(&id));
+    if (id < 0 || id >= 64 || !g_dev[id].ready)
+        return 0;
+    Device &d = g_dev[id];
+    HIPCK(hipDeviceSynchronize());
+    for (Buf *b : {&d.src, &d.dst, &d.soff, &d.doff, &d.rec, &d.ws, &d.ws_big, &d.ctr, &d.scratch}) {
+        if (b->p)
+            HIPCK(hipFree(b->p));
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    for (Buf *b : {&d.pin, &d.pin_in}) {
+        if (b->p)
+            HIPCK(hipHostFree(b->p));
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    return 0;
+}
+
 extern "C" const unsigned char *yeast_debug_table(int which, size_t *size)
 {
     if (!g_luts_ready) {

@@ -109,6 +109,13 @@ int XXH64_reset(XXH64_state_t *state, unsigned long long seed);
 int XXH64_update(XXH64_state_t *state, const void *input, size_t length);
 unsigned long long XXH64_digest(const XXH64_state_t *state);
 
+/* Give back what the library holds on the current device between calls: its input, output and
+   workspace buffers in HBM and the pinned host staging of the host-pointer calls (both sized by the
+   largest call so far; the dictionary tables, 20 MB, stay).  The next call allocates again.  No
+   counterpart in the reference, whose yeast() keeps nothing between calls; for long-running hosts after
+   an unusually large batch.  Waits for the device's outstanding work; 0 on success. */
+int yeast_trim(void);
+
 /* Diagnostics. */
 const char *yeast_last_error(void);   /* thread-local text of the last failure, "" if none */
 int yeast_device_count(void);         /* HIP devices visible, <= 0 if none */

@@ -245,6 +245,18 @@ def test_device_api_reports_small_output_region():
     assert r["check"][1] == 65536 and r["got"][1] == 0
 
 
+def test_trim_gives_buffers_back_and_the_next_calls_allocate_again():
+    meta, distinct = H.packed_streams("cfg2_streams")
+    streams = [distinct[k % len(distinct)] for k in range(300)]  # enough bytes for the pinned staging path
+    first = ba.yeast_batch(streams, ba.CHECK_XXH64)
+    ba.trim()
+    ba.trim()  # nothing held: still fine
+    assert ba.yeast_batch(streams, ba.CHECK_XXH64) == first
+    src = distinct[0]
+    assert gpu_yeast(src) == H.oracle_yeast(src)
+    assert ba.crc32c(b"123456789") == 0xe3069283  # the scratch buffer of the check calls comes back too
+
+
 def test_reference_harnesses_linked_against_the_drop_in():
     # BASELINE config 1: the reference's own juxt.c/deb.c, compiled unmodified in the build
     # container and linked against libyeast_mi355x.so (oracle/Makefile `dropin`)
