@@ -302,7 +302,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         return -1;
     }
     if (lanes == 0) /* large batches: one stream per lane; small ones: one stream per wavefront, tables in LDS */
-        lanes = env_int("YEAST_LANES", n >= 16384 ? 1 : YS_LANES_WAVE);
+        lanes = env_int("YEAST_LANES", n >= 8192 ? 1 : YS_LANES_WAVE); /* crossover: tools/kernel_crossover.py */
     if (cmp)
         lanes = 64;
     if (lanes != 1 && lanes != 8 && lanes != 16 && lanes != 64 && lanes != YS_LANES_WAVE) {
@@ -563,7 +563,7 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
         if (out)
             out[i] = nullptr;
     }
-    int lanes = env_int("YEAST_FORCE_LANES", n >= 2048 ? 0 : 64); /* the override is for the tests */
+    int lanes = env_int("YEAST_FORCE_LANES", 0); /* enqueue() chooses by n; the override is for the tests */
 
     while (!todo.empty()) {
         size_t m = todo.size();
