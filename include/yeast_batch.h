@@ -63,8 +63,8 @@ int yeast_batch(size_t n, void const *const *src, size_t *len, void **dest, size
  *   d_rec      n records, written by the kernels
  *   lanes_per_stream  0 = library default (by batch size), else 1 (batch kernel: one stream per lane) or 8, 16, 64
  *              (cooperative kernel: that many lanes of a wavefront cooperate on one stream); 65 = one wavefront
- *              per stream with the stream's prefix-code tables in LDS (lowest latency for batches of a few
- *              thousand streams)
+ *              per stream with the stream's prefix-code tables in LDS (lowest latency; the default below
+ *              8,192 streams, 1 from there on)
  * Returns 0 or a negative error (see yeast_last_error()).
  */
 int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, void *d_dst, const uint64_t *d_dst_off,
