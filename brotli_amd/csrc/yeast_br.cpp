@@ -476,8 +476,14 @@ extern "C" int yeast_broad(const void *br, size_t len, void **out, size_t *out_l
                 fill(0, pieces.size());
             else {
                 std::vector<std::thread> th;
-                for (unsigned k = 0; k < t; k++)
-                    th.emplace_back(fill, pieces.size() * k / t, pieces.size() * (k + 1) / t);
+                unsigned started = 0;
+                try {
+                    for (; started < t; started++)
+                        th.emplace_back(fill, pieces.size() * started / t, pieces.size() * (started + 1) / t);
+                } catch (...) { /* no more threads to be had: this one does the rest */
+                }
+                for (unsigned k = started; k < t; k++)
+                    fill(pieces.size() * k / t, pieces.size() * (k + 1) / t);
                 for (std::thread &x : th)
                     x.join();
             }

@@ -525,8 +525,14 @@ template <class F> static void host_parallel(size_t n, u64 bytes, F fn)
         return;
     }
     std::vector<std::thread> th;
-    for (unsigned k = 0; k < t; k++)
-        th.emplace_back(fn, n * k / t, n * (k + 1) / t);
+    unsigned started = 0;
+    try {
+        for (; started < t; started++)
+            th.emplace_back(fn, n * started / t, n * (started + 1) / t);
+    } catch (...) { /* no more threads to be had: this one does the rest */
+    }
+    for (unsigned k = started; k < t; k++)
+        fn(n * k / t, n * (k + 1) / t);
     for (std::thread &x : th)
         x.join();
 }
