@@ -124,7 +124,7 @@ def test_cfg2_batch_every_group_width(lanes, monkeypatch):
         monkeypatch.setenv("YEAST_HALF", "0" if lanes == -1 else "2")
         lanes = 1
     monkeypatch.setenv("YEAST_LANES", str(lanes))
-    many = streams * 9  # 2,304 streams: above the threshold where the batch path picks YEAST_LANES
+    many = streams * 9  # 2,304 streams; YEAST_LANES names the kernel
     res = ba.yeast_batch(many, ba.CHECK_XXH64)
     for i, r in enumerate(res):
         m = meta["streams"][i % len(streams)]
@@ -247,8 +247,13 @@ def test_device_api_reports_small_output_region():
 
 def test_trim_gives_buffers_back_and_the_next_calls_allocate_again():
     meta, distinct = H.packed_streams("cfg2_streams")
-    streams = [distinct[k % len(distinct)] for k in range(300)]  # enough bytes for the pinned staging path
+    # enough bytes for pinned staging in both directions and for the host threads that pack and cut up
+    streams = [distinct[k % len(distinct)] for k in range(600)]
     first = ba.yeast_batch(streams, ba.CHECK_XXH64)
+    for k, (rc, data, got, used, chk) in enumerate(first):
+        m = meta["streams"][k % len(distinct)]
+        assert (rc, got, used, chk) == (0, m["got"], m["len"], int(m["xxh64"], 16)), k
+        assert ba.xxh64(data) == chk if k < 4 else len(data) == got
     ba.trim()
     ba.trim()  # nothing held: still fine
     assert ba.yeast_batch(streams, ba.CHECK_XXH64) == first
