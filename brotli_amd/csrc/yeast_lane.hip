@@ -12,8 +12,11 @@
    next S streams when all of its streams are done.  S = 64 fills the wavefront; S = 32 leaves the
    upper half idle so that two wavefronts fit each SIMD and one's memory latency hides behind the
    other's work. */
+#ifndef YS_MAX_OCC
+#define YS_MAX_OCC 4 /* blocks per CU the register budget is cut for (experiments: 2 leaves S = 16 unspilled) */
+#endif
 template <int S>
-__global__ __launch_bounds__(256, 64 / S) void k_decode_lean(ys_params p)
+__global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) void k_decode_lean(ys_params p)
 {
     __shared__ Shared sh;
     __shared__ LeanLds<S> wlds[4];
