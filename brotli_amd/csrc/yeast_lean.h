@@ -126,29 +126,29 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
         }
     };
     auto refill = [&]() {
-        if (r.have <= 32) {
-            if (nq == 0) {
-                if (treq) /* the words on their way are the ones wanted */
-                    merge();
-                else {
-                    u64 t = gld64u(r.p + r.idx);
-                    a0 = (u32)t;
-                    a1 = (u32)(t >> 32);
-                    nq = 2;
-                }
-            }
-            r.w |= (u64)a0 << r.have;
-            u32 add = r.rem < 32 ? r.rem : 32;
-            r.have += add;
-            r.rem -= add;
-            if (add) {
-                r.idx++;
-                a0 = a1;
-                a1 = b0;
-                b0 = b1;
-                nq--;
+        const bool need = r.have <= 32;
+        if (need && nq == 0) { /* rare: the queue ran dry inside a pass */
+            if (treq) /* the words on their way are the ones wanted */
+                merge();
+            else {
+                u64 t = gld64u(r.p + r.idx);
+                a0 = (u32)t;
+                a1 = (u32)(t >> 32);
+                nq = 2;
             }
         }
+        /* the usual case without branches */
+        u32 add = r.rem < 32 ? r.rem : 32;
+        add = need ? add : 0;
+        r.w |= need ? (u64)a0 << (r.have & 63) : 0;
+        r.have += add;
+        r.rem -= add;
+        const bool adv = add != 0;
+        r.idx += adv;
+        a0 = adv ? a1 : a0;
+        a1 = adv ? b0 : a1;
+        b0 = adv ? b1 : b0;
+        nq -= adv;
     };
     auto bits_mid = [&](u32 n, bool &ok) -> u32 {
         if (n > r.have)
