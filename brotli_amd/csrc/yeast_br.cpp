@@ -47,13 +47,13 @@ struct Cursor {
     size_t next, len;
     unsigned get1() /* broad.c:59-64 */
     {
-        if (next == len)
+        if (next >= len)
             throw Fail{2};
         return buf[next++];
     }
     void skip(uintmax_t n) /* broad.c:46-55 */
     {
-        size_t pass = len - next;
+        size_t pass = next < len ? len - next : 0;
         if (pass > n)
             pass = (size_t)n;
         next += pass;
@@ -693,22 +693,29 @@ std::vector<size_t> braid_scan(const uint8_t *b, size_t len)
     }
     if (trail & CONTENT_LEN)
         (void)rbvar();
-    int64_t dist = 0;
+    uintmax_t dist = 0;
     if (trail & CONTENT_OFF)
-        dist = (int64_t)rbvar();
+        dist = rbvar();
     if (trail != (CONTENT_TRAIL | 7))
         if (rget1() != trail)
             throw Fail{3};
     if (at > 4 && !(trail & CONTENT_OFF))
         throw Fail{4};
+    /* The reference keeps offsets in an off_t and subtracts whatever the file says (braid.c:182, :195):
+       a distance of 2^63 and more moves the offset forward, one beyond the offset makes it negative.
+       The same arithmetic here, on unsigned values so that it is defined; an offset is only ever used
+       as a position in the buffer when it lies inside it. */
+    auto back_by = [&](uintmax_t d) { at = (int64_t)((uint64_t)at - (uint64_t)d); };
     std::vector<size_t> rev;
     rev.push_back((size_t)at);
     if (dist) {
-        at -= dist;
-        if (at >= 0)
+        back_by(dist);
+        if (at >= 0 && (uint64_t)at <= len)
             rev.push_back((size_t)at);
     }
     while (at > 4) {
+        if ((uint64_t)at >= len)
+            throw Fail{1}; /* the reference seeks there and reads end of file: braid.c:189-190, :60 */
         Cursor c{b, (size_t)at, len};
         unsigned mask;
         uintmax_t back;
@@ -722,8 +729,8 @@ std::vector<size_t> braid_scan(const uint8_t *b, size_t len)
         } catch (Fail &f) {
             throw Fail{f.code == 2 ? 1 : f.code}; /* "premature end of file" is 1 in braid.c:60 */
         }
-        at -= (int64_t)back;
-        if (at >= 0)
+        back_by(back);
+        if (at >= 0 && (uint64_t)at <= len)
             rev.push_back((size_t)at);
     }
     if (at != 4)

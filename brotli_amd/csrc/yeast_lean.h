@@ -232,6 +232,7 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
     asm volatile("" : "+v"(offI), "+v"(offL), "+v"(offD), "+v"(cur_mode), "+v"(a0));
 #ifdef YS_PROFILE
     u64 pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pmark = __builtin_readcyclecounter();
+    const u64 t_loop = __builtin_amdgcn_s_memrealtime();
     u32 npass = 0;
 #define LMARK(i) do { u64 now_ = __builtin_readcyclecounter(); pt[i] += now_ - pmark; pmark = now_; } while (0)
 #define LWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -514,6 +515,8 @@ DEV void run_lean(Ctx &c, u32 &mlen, const FlatEnv &fe)
         for (int i = 0; i < 12; i++)
             prof[i] = pt[i];
         prof[12] = npass;
+        prof[13] = t_loop - c.t_start; /* header parsing and table building, 10 ns units */
+        prof[14] = __builtin_amdgcn_s_memrealtime() - t_loop; /* the loop */
     }
 #endif
     /* meta-block end (or failure): the piece set up last was valid */

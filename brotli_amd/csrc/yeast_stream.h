@@ -77,6 +77,9 @@ struct Ctx {
     u32 rootcaps; /* root table widths (Hdr.rootcaps) */
     const Shared *sh;
     void *wl; /* LeanLds<S> of this wavefront (batch kernel only) */
+#ifdef YS_PROFILE
+    u64 t_start; /* 100 MHz clock at the start of the stream */
+#endif
 };
 
 DEV const u16 *tab_at(const Ctx &c, u32 off) { return (const u16 *)(c.ws + off); }
@@ -789,6 +792,9 @@ template <int G, bool CMP, int FLAT>
 DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub, void *wl = nullptr)
 {
     Ctx c;
+#ifdef YS_PROFILE
+    c.t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     u64 s0 = p.src_off[job], s1 = p.src_off[job + 1];
     u64 d0 = p.dst_off[job], d1 = p.dst_off[job + 1];
     c.src = p.src + s0;

@@ -23,12 +23,13 @@ offs = np.asarray(b.host_dst_off[:n + 1], dtype=np.int64)
 rows = []
 for i in range(0, n, S):
     e = int(offs[i + 1])
-    rows.append(host[e - 128:e - 128 + 104].view(np.uint64).astype(np.float64))
+    rows.append(host[e - 128:e - 128 + 120].view(np.uint64).astype(np.float64))
 m = np.stack(rows).mean(0)
 names = ["block switch", "A issue (piece loads, lookup)", "A wait", "A store piece + command", "B issue", "B wait", "B literal", "C issue",
          "C wait", "C distance", "D copy set-up", "loop head"]
 order_ = [11, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
 tot = m[:12].sum()
 print("passes per wavefront %.0f; cycles per pass %.0f" % (m[12], tot / m[12]))
+print("header and tables %.2f ms, loop %.2f ms per wavefront (mean); slowest loop %.2f ms; clock in the loop %.2f GHz" % (m[13] / 1e5, m[14] / 1e5, np.stack(rows)[:, 14].max() / 1e5, tot / (m[14] * 10)))
 for k in order_:
     print("  %-34s %8.0f cycles/pass  %5.1f%%" % (names[k], m[k] / m[12], 100 * m[k] / tot))
