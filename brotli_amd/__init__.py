@@ -55,6 +55,13 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)" % LIB_PATH)
+        # torch (used by brotli_amd.device for HBM buffers and streams) ships a HIP runtime of its own under the
+        # same soname: whichever is loaded first serves the whole process, and torch finds no GPU behind the
+        # system one.  So torch goes first whenever it is there; the C library itself never needs it.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         L.yeast.restype = ctypes.c_int
         L.yeast.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,

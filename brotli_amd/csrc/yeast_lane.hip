@@ -18,9 +18,19 @@
 template <int S>
 __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) void k_decode_lean(ys_params p)
 {
+#ifdef YS_OLD_LOOP
     __shared__ Shared sh;
     __shared__ LeanLds<S> wlds[4];
     shared_fill(sh, p.xforms, p.xdict_base);
+    const Shared *shp = &sh;
+    const TripShared *tsp = nullptr;
+#else
+    __shared__ TripShared tsh;
+    __shared__ TripLds<S> wlds[4];
+    trip_shared_fill(tsh, p.xforms, p.xdict_base);
+    const Shared *shp = nullptr; /* the header parser of the batch kernel reads none of it */
+    const TripShared *tsp = &tsh;
+#endif
     u32 lane = threadIdx.x;
     u32 wave = (blockIdx.x * blockDim.x + lane) >> 6;
     u32 slot = lane & 63;
@@ -41,7 +51,7 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
                 job = p.retry_list[job];
             else if (p.order)
                 job = p.order[job];
-            decode_stream<1, false, S>(p, job, ws, &sh, 0, &wlds[lane >> 6]);
+            decode_stream<1, false, S>(p, job, ws, shp, 0, &wlds[lane >> 6], tsp);
         }
     }
 }

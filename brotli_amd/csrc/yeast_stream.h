@@ -76,7 +76,9 @@ struct Ctx {
     const u8 *dict, *xf, *xdict;
     u32 rootcaps; /* root table widths (Hdr.rootcaps) */
     const Shared *sh;
-    void *wl; /* LeanLds<S> of this wavefront (batch kernel only) */
+    void *wl; /* per-wavefront LDS of the batch kernel (TripLds<S>) */
+    const struct TripShared *tsh; /* per-block LDS of the batch kernel */
+    const u8 *ws_base; /* start of the workspace arena (uniform): the batch kernel addresses tables from it */
 #ifdef YS_PROFILE
     u64 t_start; /* 100 MHz clock at the start of the stream */
 #endif
@@ -502,7 +504,12 @@ struct FlatEnv {
     bool ctx;
 };
 
+#ifdef YS_OLD_LOOP
 #include "yeast_lean.h"
+#else
+#define YS_XD_LENS 21 /* word lengths 4..24 */
+#include "yeast_trip.h"
+#endif
 
 /* ------------------------------------------------------------- meta-block */
 
@@ -776,11 +783,15 @@ DEV u32 metablock(Ctx &c, u32 sub)
         /* meta-blocks without block switching (the usual case for short streams) run a loop that
            carries none of that machinery; the choice is made for the whole wavefront so the
            streams stay in one loop */
+#ifdef YS_OLD_LOOP
         bool simple = c.L.num == 1 && c.I.num == 1 && c.D.num == 1;
         if (__all(simple))
             run_lean<FLAT, true>(c, mlen, fe);
         else
             run_lean<FLAT, false>(c, mlen, fe);
+#else
+        run_trip<FLAT>(c, mlen, fe);
+#endif
     }
     if (!r.rc && last && tail_nonzero(r))
         rd_fail(r, YS_INVALID); /* :1305 */
@@ -789,7 +800,8 @@ DEV u32 metablock(Ctx &c, u32 sub)
 
 /* yeast(): yeast.c:1353-1400 for one stream of the batch */
 template <int G, bool CMP, int FLAT>
-DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub, void *wl = nullptr)
+DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub, void *wl = nullptr,
+                       const struct TripShared *tsh = nullptr)
 {
     Ctx c;
 #ifdef YS_PROFILE
@@ -817,6 +829,8 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     c.rootcaps = p.rootcaps ? p.rootcaps : 0x08080808u;
     c.sh = sh;
     c.wl = wl;
+    c.tsh = tsh;
+    c.ws_base = p.ws;
     c.L.num = c.I.num = c.D.num = 1;
     rd_seek(c.r, c.src, 0);
     if (s1 - s0 >= (1u << 29))

@@ -1,0 +1,586 @@
+/*
+ * yeast_trip.h -- the command loop of the batch kernel, one stream per lane (included by
+ * yeast_stream.h; reference: the loop of yeast.c:1166-1295).
+ *
+ * One trip of the loop decodes ONE prefix-code symbol per stream -- whichever the stream needs next:
+ * an insert-and-copy symbol, a literal, a distance symbol, a block-switch type or count symbol, or
+ * the second half of a code longer than its root table -- so a trip has exactly one table lookup
+ * and one wait for memory, and every live lane uses it.  The order inside a trip is chosen for the
+ * length of the dependent chain from one lookup to the next:
+ *
+ *   1. the entry requested on the last trip arrives: consume the code and the extra bits that belong
+ *      to it (insert/copy extra bits, distance extra bits) from a 64-bit funnel over the input words;
+ *   2. decide what the stream decodes next and where that table is (literal context -> table through
+ *      the wavefront's LDS map), and REQUEST THAT ENTRY AT ONCE;
+ *   3. under that request's latency, do everything else: the distance value and the ring buffer
+ *      (distance() yeast.c:761-789), the static dictionary reference (dict_word() yeast.c:908-949, a
+ *      copy from the expanded dictionary), the copy set-up and its validity checks, the store of the
+ *      piece loaded on the last trip and the load of the next one.
+ *
+ * Bytes are moved by a per-stream copy engine in pieces of up to 16 bytes: one 16-byte load when the
+ * piece is set up, one 16-byte store a trip later; the literal context after a copy comes from the
+ * loaded registers.  Overlapping copies (byte-serial semantics, yeast.c:1285-1293) go in pieces no
+ * longer than their period, the period doubling with every whole period written.  A copy of up to 16
+ * bytes (98 % of the copies of text) costs no trip of its own: the next command's symbol is requested
+ * before the copy is set up (speculatively: when the copy turns out to need more pieces, or the
+ * meta-block ends with it, the entry is dropped).
+ *
+ * The code is written without divergent branches: every step is computed for all lanes and selected,
+ * memory operations are masked, and the rare cases (block switches, the last bytes of an output
+ * region, a second input word in one trip) sit behind wavefront-uniform branches.
+ */
+#ifndef YEAST_TRIP_H
+#define YEAST_TRIP_H
+
+/* per-wavefront LDS: [index][stream], so the streams of a wavefront use different banks */
+template <int S>
+struct TripLds {
+    u16 lt[64 * S]; /* literal table (byte offset >> 4) per context, current literal block type */
+    u16 dt[4 * S];  /* distance table per distance context, current distance block type */
+    u32 bt[6 * S];  /* block-switch tables (byte offsets): type code, count code of the three categories */
+};
+
+/* LDS image shared by the wavefronts of a block */
+struct TripShared {
+    u64 cmd[704];     /* per insert-and-copy symbol: insert base | insert extra << 16 | copy extra << 24, then
+                         copy base | distance context << 16  (insert_length()/copy_length() yeast.c:652-693, :1254) */
+    u16 kctx[4 * 256]; /* per context mode and byte value: contribution to context_id() (yeast.c:698-755) as the
+                          last byte (low byte) and as the byte before it (high byte) */
+    u32 xbt[121 * 21]; /* expanded dictionary: offset of (transform, word length) | entry size << 25 */
+};
+
+DEV void trip_shared_fill(TripShared &ts, const u8 *xforms, const u32 *xbase)
+{
+    for (u32 i = threadIdx.x; i < 704; i += blockDim.x) {
+        u64 ce = c_cmd_tab[i];
+        u32 ib = (u32)ce & 0xffff, n1 = ((u32)ce >> 16) & 0xff, cb = (u32)(ce >> 24) & 0xffff, n2 = (u32)(ce >> 40);
+        u32 dctx = cb > 4 ? 3 : cb - 2;
+        ts.cmd[i] = (u64)(ib | (n1 << 16) | (n2 << 24)) | ((u64)(cb | (dctx << 16)) << 32);
+    }
+    for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) {
+        u32 mode = i >> 8, b = i & 255;
+        u32 l0 = c_ctx_lut[b], l1 = c_ctx_lut[256 + b], l2 = c_ctx_lut[512 + b];
+        u32 f1 = mode == 0 ? (b & 63) : mode == 1 ? (b >> 2) : mode == 2 ? l0 : (l2 << 3);
+        u32 f2 = mode < 2 ? 0 : mode == 2 ? l1 : l2;
+        ts.kctx[i] = (u16)(f1 | (f2 << 8));
+    }
+    for (u32 i = threadIdx.x; i < 121 * 21; i += blockDim.x) {
+        u32 t = i / 21, L = i % 21 + 4;
+        const u8 *rec = xforms + 20 * t;
+        u32 op = rec[0], omit = rec[1], plen = rec[2], slen = rec[3];
+        u32 wlen = (op == 3 || op == 4) ? (L > omit ? L - omit : 0) : L;
+        ts.xbt[i] = xbase[i] | ((plen + wlen + slen) << 25);
+    }
+    __syncthreads();
+}
+
+/* global memory through a wavefront-uniform base and a 32-bit lane offset */
+DEV u32 sld16(const u8 *base, u32 off) { return *(const GAS u16 *)(base + (u64)off); }
+DEV u32 sld32(const u8 *base, u32 off) { return *(const GAS u32 *)(base + (u64)off); }
+DEV u32 sld8(const u8 *base, u32 off) { return *(const GAS u8 *)(base + (u64)off); }
+
+#define YT_CMD 0u
+#define YT_LIT 1u
+#define YT_DIST 2u
+#define YT_BT 3u   /* block-switch type symbol */
+#define YT_BC 4u   /* block-switch count symbol */
+#define YT_COPY 5u /* a copy of more than one piece in progress: nothing to decode */
+#define YT_END 6u
+
+/* What the loop takes from the stream's state and hands back.  The loop is an out-of-line function so that it
+   has the register file to itself: the rest of the per-stream state (Ctx, the header parser's variables, the
+   kernel's arguments) waits on the stack instead of crowding the loop into spills. */
+struct TripIn {
+    const u8 *ws_base, *src, *out, *xdict;
+    u8 *outp;
+    LAS void *wl;
+    LAS const TripShared *ts;
+    u32 wso, rootcaps, flags; /* flags: 1 literal context map in use, 2 distance context map in use */
+    u32 postfix, direct, wsize, cap, mlen;
+    u32 bitpos, total;
+    u32 p1, p2, r0, r1, r2, r3;
+    u32 w_ltab, offL0, offD0, cur_mode;
+    u32 num3, left0, left1, left2;
+    u32 bt0, bt1, bt2, bt3, bt4, bt5;
+#ifdef YS_PROFILE
+    u64 t_start;
+#endif
+};
+struct TripOut {
+    u8 *outp;
+    u32 r0, r1, r2, r3, mlen, rc, dry, pos;
+};
+
+template <int S>
+NOINL TripOut run_trip_fn(TripIn a)
+{
+    LAS TripLds<S> *wl = (LAS TripLds<S> *)a.wl;
+    LAS const TripShared *ts = a.ts;
+    const u32 slot = threadIdx.x & 63;
+    const u8 *const wsb = (const u8 *)uni64((u64)a.ws_base);
+    const u8 *const xdict = (const u8 *)uni64((u64)a.xdict);
+    const u32 wso = a.wso;
+    const u32 rootcaps = uni(a.rootcaps);
+    const u32 rootL = (rootcaps >> 8) & 255, rootI = (rootcaps >> 16) & 255, rootD = rootcaps >> 24;
+    const bool ctx = a.flags & 1;
+    const bool dmap = a.flags & 2;
+    const u32 postfix = a.postfix, direct = a.direct, wsize = a.wsize;
+    const u32 out_lo = (u32)(uintptr_t)a.out;
+    const u32 cap = a.cap;
+    u32 mlen = a.mlen;
+    u32 rc = 0, dry = 0;
+
+    /* ---- per-type tables of the current block types ---- */
+    const u32 w_ltab = a.w_ltab;
+    auto load_lt = [&](u32 type) {
+#pragma clang loop unroll(disable)
+        for (u32 n = 0; n < 64; n++)
+            wl->lt[n * S + slot] = (u16)(sld32(wsb, w_ltab + ((type << 6) + n) * 4) >> 4);
+    };
+    auto load_dt = [&](u32 type) {
+#pragma clang loop unroll(disable)
+        for (u32 n = 0; n < 4; n++)
+            wl->dt[n * S + slot] = (u16)(sld32(wsb, wso + YS_WS_DTAB + ((type << 2) + n) * 4) >> 4);
+    };
+    if (ctx)
+        load_lt(0);
+    if (dmap)
+        load_dt(0);
+    u32 offI = wso + sld32(wsb, wso + YS_WS_ITAB);
+    const u32 offL0 = a.offL0, offD0 = a.offD0;
+    u32 kmode = a.cur_mode << 8; /* index of the mode's row in kctx */
+    /* block switching of the three categories (CMD 0, LIT 1, DIST 2), one byte each: number of types - 1,
+       current type, previous type; the counts of symbols left in the current blocks */
+    const u32 num3 = a.num3;
+    u32 type3 = 0, prev3 = 0x010101u;
+    u32 left0 = a.left0, left1 = a.left1, left2 = a.left2;
+    const bool switching = num3 != 0;
+    if (switching) {
+        wl->bt[0 * S + slot] = a.bt0;
+        wl->bt[1 * S + slot] = a.bt1;
+        wl->bt[2 * S + slot] = a.bt2;
+        wl->bt[3 * S + slot] = a.bt3;
+        wl->bt[4 * S + slot] = a.bt4;
+        wl->bt[5 * S + slot] = a.bt5;
+    }
+    const bool any_switching = __any(switching);
+
+    /* ---- input: six words behind the bit offset bo (< 32 at the head of a trip); 64 bits from bo come out of
+       d0..d2 by two funnel shifts.  Topped up by one 8-byte load per trip while four words or fewer are held. */
+    u32 d0, d1, d2, d3, d4, d5, nq = 6, bo;
+    const u8 *ip;
+    u32 endrel; /* bits from bit 0 of d0 to the end of the stream */
+    {
+        u32 bitpos = a.bitpos;
+        const u8 *at = a.src + (bitpos >> 3);
+        u32 mis = (u32)(uintptr_t)at & 3;
+        ip = at - mis;
+        bo = mis * 8 + (bitpos & 7);
+        endrel = a.total - bitpos + bo;
+        u64 q0 = gld64u(ip), q1 = gld64u(ip + 8), q2 = gld64u(ip + 16);
+        d0 = (u32)q0; d1 = (u32)(q0 >> 32); d2 = (u32)q1; d3 = (u32)(q1 >> 32); d4 = (u32)q2; d5 = (u32)(q2 >> 32);
+        ip += 24;
+    }
+    u64 tq = 0; /* the top-up in flight (requested while nq <= 4, merged at the head of the next trip) */
+
+    /* ---- output and copy engine ---- */
+    u8 *op = a.outp;
+    u32 p1 = a.p1 & 255, p2 = a.p2 & 255;
+    u32 r0 = a.r0, r1 = a.r1, r2 = a.r2, r3 = a.r3;
+    u32 insert = 0, copy = 0, implicit = 0, dctx = 0;
+    u32 dsym = 0, dxv = 0;
+    const u8 *csrc = a.outp; /* copy in progress: source of the next piece, bytes left, period limit */
+    u32 crem = 0, cD = 0;
+    u32x4 pv = {0, 0, 0, 0}; /* the piece loaded on the last trip; it goes to op - pn */
+    u32 pn = 0;
+
+    /* ---- the lookup in flight ---- */
+    u32 st = YT_CMD, cat = 0;
+    u32 la = 0, lw = 0, lk = 0; /* table base (offset from wsb), index width; lk: root width of the code whose
+                                   second half is being looked up, else 0 */
+    u32 lo = 0, hi = 0;         /* 64 bits of input from bo */
+    u32 e = 0;
+
+    /* what a stream decodes next: w = category wanted (0..2).  A used-up block count turns it into a block
+       switch first (yeast.c:1168-1180, 1192-1204, 1239-1251). */
+    auto enter = [&](bool on, u32 w, u32 off_w, u32 l0, u32 l1, u32 l2) {
+        /* off_w: table of category w; roots by category */
+        u32 root_w = w == YT_CMD ? rootI : w == YT_LIT ? rootL : rootD;
+        u32 nst = w, nla = off_w, nlw = root_w;
+        if (any_switching) {
+            u32 left = w == YT_CMD ? l0 : w == YT_LIT ? l1 : l2;
+            bool sw = ((num3 >> (8 * w)) & 255) != 0 && left == 0;
+            if (__any(on && sw)) {
+                u32 tt = wl->bt[(2 * w) * S + slot];
+                nla = sw ? wso + tt : nla;
+                nlw = sw ? 8u : nlw;
+                nst = sw ? YT_BT : nst;
+                cat = on && sw ? w : cat;
+            }
+        }
+        st = on ? nst : st;
+        la = on ? nla : la;
+        lw = on ? nlw : lw;
+    };
+    /* move whole words out of the queue while bo >= 32 (once; a second time behind a uniform branch) */
+    auto advance = [&]() {
+        bool adv = bo >= 32;
+        d0 = adv ? d1 : d0;
+        d1 = adv ? d2 : d1;
+        d2 = adv ? d3 : d2;
+        d3 = adv ? d4 : d3;
+        d4 = adv ? d5 : d4;
+        nq -= adv;
+        u32 step = adv ? 32u : 0u;
+        endrel -= step;
+        bo -= step;
+    };
+    /* request the entry of the lookup described by (la, lw) for the lanes in `on` */
+    auto request = [&](bool on) {
+        advance();
+        if (__any(bo >= 32))
+            advance();
+        lo = __builtin_amdgcn_alignbit(d1, d0, bo);
+        hi = __builtin_amdgcn_alignbit(d2, d1, bo);
+        if (on)
+            e = sld16(wsb, la + (__builtin_amdgcn_ubfe(lo, 0, lw) << 1));
+        if (nq <= 4 && st != YT_END)
+            tq = gld64u(ip);
+    };
+
+    enter(true, YT_CMD, offI, left0, left1, left2);
+    request(true);
+    asm volatile("" : "+v"(offI), "+v"(kmode), "+v"(d0), "+v"(d5));
+
+#ifdef YS_PROFILE
+    u32 ntrip = 0;
+    const u64 t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
+    while (__any(st != YT_END)) {
+#ifdef YS_PROFILE
+        ntrip++;
+#endif
+        /* ---- 1. the top-up and the entry ---- */
+        {
+            const bool got2 = nq <= 4 && st != YT_END; /* the condition the request was made under */
+            u32 t0 = (u32)tq, t1 = (u32)(tq >> 32);
+            d3 = got2 && nq == 3 ? t0 : d3;
+            d4 = got2 ? (nq == 3 ? t1 : t0) : d4;
+            d5 = got2 && nq == 4 ? t1 : d5;
+            ip += got2 ? 8 : 0;
+            nq += got2 ? 2 : 0;
+        }
+        const bool active = st <= YT_BC;
+        u32 l = e & 15, sym = e >> 4;
+        const bool is_link = active && lk == 0 && l > lw;
+        u32 nb = is_link ? lw : l - lk;
+        nb = active ? nb : 0;
+        const u64 t64 = (((u64)hi << 32) | lo) >> nb; /* the bits behind the code */
+        const u32 t = (u32)t64;
+        bo += nb;
+        bool eof = bo > endrel;
+        const bool done = active && !is_link && !eof;
+        la = is_link ? la + (sym << 1) : la;
+        const u32 lw_link = l - lw;
+        lk = is_link ? lw : 0;
+        lw = is_link ? lw_link : lw;
+
+        /* ---- insert-and-copy symbol: insert_length(), copy_length() yeast.c:652-693 ---- */
+        const bool dC = done && st == YT_CMD;
+        {
+            u64 ce = ts->cmd[sym < 704 ? sym : 0];
+            u32 clo = (u32)ce, chi = (u32)(ce >> 32);
+            u32 n1 = (clo >> 16) & 0xff, n2 = clo >> 24;
+            u32 x1 = __builtin_amdgcn_ubfe(t, 0, n1);
+            u32 x2 = __builtin_amdgcn_ubfe((u32)(t64 >> n1), 0, n2);
+            insert = dC ? (clo & 0xffff) + x1 : insert;
+            copy = dC ? (chi & 0xffff) + x2 : copy;
+            dctx = dC ? chi >> 16 : dctx;
+            implicit = dC ? (u32)(sym < 128) : implicit;
+            bo += dC ? n1 + n2 : 0;
+            left0 -= dC && switching;
+        }
+        /* ---- literal ---- */
+        const bool dL = done && st == YT_LIT;
+        if (dL)
+            gst8(op, sym);
+        op += dL;
+        p2 = dL ? p1 : p2;
+        p1 = dL ? sym : p1;
+        insert -= dL;
+        left1 -= dL && switching;
+        /* ---- distance symbol: the extra bits now, the value below ---- */
+        const bool dD = done && st == YT_DIST;
+        {
+            u32 dn = sym - direct - 16;
+            u32 dx = sym >= 16 + direct ? 1 + (dn >> (postfix + 1)) : 0;
+            dx = dx > 24 ? 24 : dx; /* cannot be: the alphabet ends at 16 + direct + (48 << postfix) */
+            dsym = dD ? sym : dsym;
+            dxv = dD ? __builtin_amdgcn_ubfe(t, 0, dx) : dxv;
+            bo += dD ? dx : 0;
+            left2 -= dD && switching;
+        }
+        eof = eof || ((dC || dD) && bo > endrel);
+        const bool over = dC && !eof && insert > mlen; /* :1189 */
+        mlen -= dC && !eof && !over ? insert : 0;
+        {
+            const bool bad = (active && eof) || over;
+            dry = active && eof && !rc ? 1 : dry;
+            rc = bad && !rc ? (eof ? (u32)YS_EOF : (u32)YS_INVALID) : rc;
+        }
+
+        /* ---- the piece that arrived: the last two bytes written are the literal context ---- */
+        {
+            u32 k = pn >= 2 ? pn - 2 : 0, ki = k >> 2;
+            const bool k1b = ki & 1, k2b = ki & 2;
+            u32 a01 = k1b ? pv.y : pv.x, a23 = k1b ? pv.w : pv.z, b01 = k1b ? pv.z : pv.y, b23 = k1b ? 0u : pv.w;
+            u32 a = k2b ? a23 : a01, b = k2b ? b23 : b01;
+            u32 pe = __builtin_amdgcn_alignbyte(b, a, k & 3);
+            u32 n2 = pn >= 2 ? pe & 255 : p1, n1 = pn >= 2 ? (pe >> 8) & 255 : pv.x & 255;
+            p2 = pn ? n2 : p2;
+            p1 = pn ? n1 : p1;
+        }
+
+        /* ---- block switch symbols (rare) ---- */
+        bool redo = false; /* the lookup of the category the switch was for */
+        if (any_switching && __any(done && st >= YT_BT)) {
+            const bool dT = done && st == YT_BT, dN = done && st == YT_BC;
+            u32 sh = 8 * cat;
+            u32 k_type = (type3 >> sh) & 255, k_num = ((num3 >> sh) & 255) + 1, k_prev = (prev3 >> sh) & 255;
+            u32 n = sym > 1 ? sym - 2 : sym ? (k_type + 1 == k_num ? 0 : k_type + 1) : k_prev;
+            n = n >= k_num ? 0 : n; /* only after a read failure; keeps table indices in range */
+            prev3 = dT ? (prev3 & ~(255u << sh)) | (k_type << sh) : prev3;
+            type3 = dT ? (type3 & ~(255u << sh)) | (n << sh) : type3;
+            /* block_length(): yeast.c:550-567 */
+            u32 s = sym, base, extra;
+            if (s < 4) { base = 1 + 4 * s; extra = 2; }
+            else if (s < 8) { base = 17 + 8 * (s - 4); extra = 3; }
+            else if (s < 12) { base = 49 + 16 * (s - 8); extra = 4; }
+            else if (s < 16) { base = 113 + 32 * (s - 12); extra = 5; }
+            else if (s < 18) { base = 241 + 64 * (s - 16); extra = 6; }
+            else if (s >= 25) { base = 16625; extra = 24; }
+            else { extra = s - 11; base = 369 + ((1u << (s - 11)) - 128); }
+            u32 cnt = base + __builtin_amdgcn_ubfe(t, 0, extra);
+            bo += dN ? extra : 0;
+            const bool e2 = dN && bo > endrel;
+            dry = e2 && !rc ? 1 : dry;
+            rc = e2 && !rc ? (u32)YS_EOF : rc;
+            const bool okN = dN && !e2;
+            left0 = okN && cat == YT_CMD ? cnt : left0;
+            left1 = okN && cat == YT_LIT ? cnt : left1;
+            left2 = okN && cat == YT_DIST ? cnt : left2;
+            if (okN) { /* the new type's tables */
+                u32 ty = (type3 >> sh) & 255;
+                if (cat == YT_CMD)
+                    offI = wso + sld32(wsb, wso + YS_WS_ITAB + ty * 4);
+                else if (cat == YT_LIT) {
+                    kmode = sld8(wsb, wso + YS_WS_MODE + ty) << 8;
+                    if (ctx)
+                        load_lt(ty);
+                } else if (dmap)
+                    load_dt(ty);
+            }
+            if (dT) { /* next: the count symbol */
+                la = wso + wl->bt[(2 * cat + 1) * S + slot];
+                lw = 8;
+                st = YT_BC;
+            }
+            redo = okN;
+        }
+        asm volatile("" : "+v"(offI), "+v"(kmode));
+
+        /* ---- 2. what comes next ---- */
+        /* the copy in progress ends with the piece set up on this trip */
+        u32 m = crem < 16 ? crem : 16;
+        m = m < cD ? m : cD;
+        const bool fin = st == YT_COPY && m == crem;
+        /* category wanted by the streams that finished a symbol (or a block switch, or a copy) */
+        const bool lits = insert != 0;
+        const bool after_lits = (dC || dL) && !lits; /* literals of the command done (or none) */
+        const bool ends = (dL && !lits && mlen == 0) || (fin && mlen == 0); /* :1227, :1295 */
+        const bool start = !rc && ((after_lits && !ends && implicit) || dD); /* a copy begins on this trip */
+        const bool wantL = ((dC || dL) && lits) || (redo && cat == YT_LIT);
+        const bool wantD = (after_lits && !ends && !implicit) || (redo && cat == YT_DIST);
+        const bool wantC = start || (fin && mlen != 0) || (redo && cat == YT_CMD);
+        /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
+           distance context -> table (yeast.c:1253-1257 through dt) */
+        u32 offL = offL0, offD = offD0;
+        {
+            u32 f1 = ((const LAS u8 *)ts->kctx)[(kmode + p1) * 2];
+            u32 f2 = ((const LAS u8 *)ts->kctx)[(kmode + p2) * 2 + 1];
+            u32 cid = f1 | f2;
+            u32 mi = wantD ? 64 * S + dctx * S : cid * S; /* dt lies behind lt */
+            u32 o = (u32)((const LAS u16 *)wl->lt)[mi + slot] << 4;
+            offL = ctx ? wso + o : offL;
+            offD = dmap ? wso + o : offD;
+        }
+        const bool want = (wantL || wantD || wantC) && !rc;
+        {
+            u32 w = wantL ? YT_LIT : wantD ? YT_DIST : YT_CMD;
+            u32 off_w = wantL ? offL : wantD ? offD : offI;
+            enter(want, w, off_w, left0, left1, left2);
+        }
+        st = rc || ends ? YT_END : st;
+        const bool look = st <= YT_BC && !rc;
+        request(look);
+
+        /* ---- 3. under that request: bytes ---- */
+        /* the piece loaded on the last trip: a whole unit; the excess is overwritten by what follows */
+        if (pn)
+            gst128u(op - pn, pv);
+        pn = 0;
+        const u32 got = (u32)(uintptr_t)op - out_lo;
+        {
+            /* distance(): yeast.c:761-789 (every lane computes it; the lanes in `start` use it) */
+            u32 ds = dsym;
+            u32 back = ds < 4 ? ds : (ds >= 10 ? 1u : 0u);
+            u32 r01 = (back & 1) ? r1 : r0, r23 = (back & 1) ? r3 : r2;
+            u32 rv = (back & 2) ? r23 : r01;
+            u32 k = ds - (ds < 10 ? 4u : 10u); /* -1 +1 -2 +2 -3 +3 */
+            i32 dl = (i32)(k >> 1) + 1;
+            dl = (k & 1) ? dl : -dl;
+            dl = ds < 4 ? 0 : dl;
+            i32 dring = (i32)rv + dl;
+            u32 dn = ds - direct - 16;
+            u32 dx = 1 + (dn >> (postfix + 1));
+            dx = dx > 24 ? 24 : dx;
+            u32 o2 = ((2 + ((dn >> postfix) & 1)) << dx) - 4;
+            i32 dcode = (i32)(((o2 + dxv) << postfix) + (dn & ((1u << postfix) - 1)) + direct + 1); /* <= 2^30 + 121 */
+            i32 dv = ds < 16 + direct ? (i32)ds - 15 : dcode;
+            dv = ds < 16 ? dring : dv;
+            dv = dD ? dv : (i32)r0; /* yeast.c:1234-1236: the last distance, not pushed again */
+            const u32 dist = (u32)dv;
+            bool bad = dv <= 0; /* zero: see DESIGN.md; negative: the reference's code 3 */
+            const u32 maxd = got < wsize ? got : wsize;
+            const bool push = start && dD && ds != 0 && !bad && dist <= maxd;
+            r3 = push ? r2 : r3;
+            r2 = push ? r1 : r2;
+            r1 = push ? r0 : r1;
+            r0 = push ? dist : r0;
+            /* the copy: from the window, or a static dictionary word (dict_word() yeast.c:908-949) */
+            const bool isd = !bad && dist > maxd;
+            u32 id = dist - maxd - 1;
+            u32 ci = copy - 4; /* NDBITS[copy] (yeast.c:916-919), four bits per word length */
+            u32 ndlo = (u32)(0x7877899aaaaabbaaull >> (4 * (ci & 15))) & 15, ndhi = (0x55667u >> (4 * (ci & 7))) & 15;
+            u32 nd = ci < 16 ? ndlo : ndhi;
+            u32 xform = id >> nd;
+            const bool dbad = isd && (ci > 20 || xform >= 121); /* :921-924, :929-930 */
+            u32 xi = (xform < 121 ? xform : 0) * YS_XD_LENS + (ci > 20 ? 0 : ci);
+            u32 xe = ts->xbt[xi];
+            u32 total = xe >> 25;
+            u32 n = isd ? total : copy;
+            bad = bad || dbad || n > mlen; /* :1269, :1283 */
+            bad = bad && start;
+            rc = bad && !rc ? (u32)YS_INVALID : rc;
+            const u8 *sd = xdict + (u64)((xe & 0x1ffffffu) + (id & ((1u << nd) - 1)) * total);
+            const u8 *sw = op - dist;
+            const bool go = start && !bad;
+            csrc = go ? (isd ? sd : sw) : csrc;
+            cD = go ? (isd ? 0x40000000u : dist) : cD;
+            crem = go ? n : crem;
+            mlen -= go ? n : 0;
+            u32 m2 = crem < 16 ? crem : 16;
+            m2 = m2 < cD ? m2 : cD;
+            m = start ? m2 : m;
+            /* the speculative request stands if the copy is one piece and the meta-block goes on */
+            u32 nst = mlen == 0 && m == crem ? YT_END : m == crem ? st : YT_COPY;
+            nst = bad ? YT_END : nst;
+            st = start ? nst : st;
+        }
+        /* the next piece of the copy in progress: requested now, stored on the next trip */
+        {
+            const bool piece = crem != 0;
+            const bool tail = piece && got + 16 > cap; /* the last bytes of the output region: nothing is written beyond it */
+            if (__any(tail)) {
+                if (tail) { /* byte by byte, at once */
+                    u32 last1 = p1, last2 = p2;
+                    for (u32 j = 0; j < m; j++) {
+                        u32 v = gld8(csrc + j);
+                        gst8(op + j, v);
+                        last2 = last1;
+                        last1 = v;
+                    }
+                    p1 = last1;
+                    p2 = last2;
+                }
+            }
+            if (piece && !tail)
+                pv = gld128u_nt(csrc); /* read once, far back in the output: not worth a place in L2 */
+            m = piece ? m : 0;
+            op += m;
+            pn = tail ? 0 : m;
+            crem -= m;
+            const bool whole = m == cD; /* a whole period is written: twice as far back is the same data */
+            cD = whole ? cD * 2 : cD;
+            csrc += whole ? 0 : m;
+        }
+    }
+#ifdef YS_PROFILE
+    if ((threadIdx.x & 63) == 0 && cap >= 128) { /* the profile build's output bytes are not meant to be looked at */
+        u64 *prof = (u64 *)(a.out + cap - 128);
+        prof[12] = ntrip;
+        prof[13] = t_loop - a.t_start;
+        prof[14] = __builtin_amdgcn_s_memrealtime() - t_loop;
+    }
+#endif
+    /* meta-block end (or failure): the piece set up last was valid */
+    if (pn)
+        gst128u(op - pn, pv);
+    TripOut o;
+    o.outp = op;
+    o.r0 = r0; o.r1 = r1; o.r2 = r2; o.r3 = r3;
+    o.mlen = mlen;
+    o.rc = rc;
+    o.dry = dry;
+    o.pos = a.total - endrel + bo;
+    return o;
+}
+
+template <int S>
+DEV void run_trip(Ctx &c, u32 &mlen, const FlatEnv &fe)
+{
+    Rd &r = c.r;
+    TripIn a;
+    a.ws_base = c.ws_base; a.src = c.src; a.out = c.out; a.xdict = c.xdict;
+    a.outp = c.outp;
+    a.wl = (LAS void *)c.wl;
+    a.ts = (LAS const TripShared *)c.tsh;
+    a.wso = (u32)(c.ws - c.ws_base);
+    a.rootcaps = c.rootcaps;
+    a.flags = (fe.ctx ? 1u : 0u) | (c.dist_codes > 1 ? 2u : 0u);
+    a.postfix = c.postfix; a.direct = c.direct; a.wsize = c.wsize;
+    a.cap = c.cap > 0xffffffffull ? 0xffffffffu : (u32)c.cap;
+    a.mlen = mlen;
+    a.bitpos = rd_pos(r); a.total = r.total;
+    a.p1 = c.p1; a.p2 = c.p2; a.r0 = c.r0; a.r1 = c.r1; a.r2 = c.r2; a.r3 = c.r3;
+    a.w_ltab = a.wso + (u32)((const u8 *)fe.lit_tab - c.ws);
+    a.offL0 = a.wso + fe.offL0; a.offD0 = a.wso + fe.offD0;
+    a.cur_mode = fe.cur_mode;
+    a.num3 = (c.I.num - 1) | ((c.L.num - 1) << 8) | ((c.D.num - 1) << 16);
+    a.left0 = c.I.left; a.left1 = c.L.left; a.left2 = c.D.left;
+    a.bt0 = c.I.t_type; a.bt1 = c.I.t_count; a.bt2 = c.L.t_type; a.bt3 = c.L.t_count; a.bt4 = c.D.t_type; a.bt5 = c.D.t_count;
+#ifdef YS_PROFILE
+    a.t_start = c.t_start;
+#endif
+    TripOut o = run_trip_fn<S>(a);
+    c.outp = o.outp;
+    c.r0 = o.r0; c.r1 = o.r1; c.r2 = o.r2; c.r3 = o.r3;
+    mlen = o.mlen;
+    group_sync_mem();
+    { /* literal context for the next meta-block */
+        u64 got = got_of(c);
+        c.p1 = got >= 1 ? gld8(c.outp - 1) : 0;
+        c.p2 = got >= 2 ? gld8(c.outp - 2) : 0;
+    }
+    /* hand the position back to the header reader */
+    if (o.rc) {
+        r.rc = o.rc;
+        r.dry = o.dry;
+        r.fpos = o.dry ? r.total : o.pos;
+        r.have = 0;
+        r.rem = 0;
+    } else
+        rd_seek(r, c.src, o.pos);
+}
+
+#endif
