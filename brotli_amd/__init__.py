@@ -44,13 +44,20 @@ class Record(ctypes.Structure):
 
 
 _lib = None
+_knobs = None
 _libc = ctypes.CDLL(None)
 _libc.free.argtypes = [ctypes.c_void_p]
 
 
 def lib() -> ctypes.CDLL:
     """Load libyeast_mi355x.so; raise loudly if it has not been built."""
-    global _lib
+    global _lib, _knobs
+    if _lib is not None:
+        # the library reads its YEAST_* knobs once; tests and tools that change them between calls say so
+        now = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("YEAST_")))
+        if now != _knobs:
+            _knobs = now
+            _lib.yeast_reload_knobs()
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -63,6 +70,8 @@ def lib() -> ctypes.CDLL:
         except Exception:
             pass
         L = ctypes.CDLL(LIB_PATH)
+        L.yeast_reload_knobs.restype = None
+        _knobs = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("YEAST_")))
         L.yeast.restype = ctypes.c_int
         L.yeast.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
                             ctypes.POINTER(ctypes.c_size_t), ctypes.c_int]

@@ -200,11 +200,19 @@ NOINL TripOut run_trip_fn(TripIn a)
                                    second half is being looked up, else 0 */
     u32 lo = 0, hi = 0;         /* 64 bits of input from bo */
     u32 e = 0;
+    u32 treq = 0;               /* a top-up is in flight */
+    u32 after = YT_DIST;        /* what follows the literals of the command: YT_DIST, or YT_START = the copy */
+    u32 cx = 0, cxn = 0;        /* the last two bytes of the piece requested on the last trip (cxn of them) */
+#define YT_START 8u
+#ifdef YS_PROFILE
+#define TMARK(i) do { u64 now_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); pt[i] += now_ - plast; plast = now_; } while (0)
+#else
+#define TMARK(i) do { } while (0)
+#endif
 
     /* what a stream decodes next: w = category wanted (0..2).  A used-up block count turns it into a block
        switch first (yeast.c:1168-1180, 1192-1204, 1239-1251). */
     auto enter = [&](bool on, u32 w, u32 off_w, u32 l0, u32 l1, u32 l2) {
-        /* off_w: table of category w; roots by category */
         u32 root_w = w == YT_CMD ? rootI : w == YT_LIT ? rootL : rootD;
         u32 nst = w, nla = off_w, nlw = root_w;
         if (any_switching) {
@@ -235,7 +243,7 @@ NOINL TripOut run_trip_fn(TripIn a)
         endrel -= step;
         bo -= step;
     };
-    /* request the entry of the lookup described by (la, lw) for the lanes in `on` */
+    /* request the entry of the lookup described by (la, lw) for the lanes in `on`, and the input top-up */
     auto request = [&](bool on) {
         advance();
         if (__any(bo >= 32))
@@ -244,7 +252,8 @@ NOINL TripOut run_trip_fn(TripIn a)
         hi = __builtin_amdgcn_alignbit(d2, d1, bo);
         if (on)
             e = sld16(wsb, la + (__builtin_amdgcn_ubfe(lo, 0, lw) << 1));
-        if (nq <= 4 && st != YT_END)
+        treq = nq <= 4 && st != YT_END;
+        if (treq)
             tq = gld64u(ip);
     };
 
@@ -254,15 +263,44 @@ NOINL TripOut run_trip_fn(TripIn a)
 
 #ifdef YS_PROFILE
     u32 ntrip = 0;
+    u64 pwait = 0, pbody = 0, plast;
+    u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(plast)::"memory");
     const u64 t_loop = __builtin_amdgcn_s_memrealtime();
 #endif
+    /* No stream needs more trips than this (a trip that neither writes a byte nor reads a bit is a block switch
+       or the symbol of a one-symbol code, a bounded number per byte written): the loop ends whatever the data.
+       A stream cut short by it is handed to the retry pass like one whose tables did not fit. */
+    u32 budget;
+    {
+        u64 l64 = 16ull * mlen + 2ull * endrel + 256;
+        u32 lim = l64 > 0xffffffffull ? 0xffffffffu : (u32)l64;
+        budget = 0;
+        for (u64 todo = __ballot(1); todo; todo &= todo - 1) {
+            u32 v = (u32)__builtin_amdgcn_readlane((int)lim, (int)__builtin_ctzll(todo));
+            budget = v > budget ? v : budget;
+        }
+    }
     while (__any(st != YT_END)) {
+        if (--budget == 0) {
+            rc = st != YT_END && !rc ? (u32)YS_WORKSPACE : rc;
+            break;
+        }
 #ifdef YS_PROFILE
         ntrip++;
-#endif
-        /* ---- 1. the top-up and the entry ---- */
         {
-            const bool got2 = nq <= 4 && st != YT_END; /* the condition the request was made under */
+            u64 ta, tb;
+            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta)::"memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb)::"memory");
+            pwait += tb - ta;
+            pt[7] += ta - plast;
+            plast = tb;
+        }
+#endif
+        /* ================= 1. the entry arrives: consume it ================= */
+        {
+            const bool got2 = treq != 0;
             u32 t0 = (u32)tq, t1 = (u32)(tq >> 32);
             d3 = got2 && nq == 3 ? t0 : d3;
             d4 = got2 ? (nq == 3 ? t1 : t0) : d4;
@@ -284,64 +322,46 @@ NOINL TripOut run_trip_fn(TripIn a)
         const u32 lw_link = l - lw;
         lk = is_link ? lw : 0;
         lw = is_link ? lw_link : lw;
+        const bool dC = done && st == YT_CMD, dL = done && st == YT_LIT, dD = done && st == YT_DIST;
 
-        /* ---- insert-and-copy symbol: insert_length(), copy_length() yeast.c:652-693 ---- */
-        const bool dC = done && st == YT_CMD;
+        /* insert-and-copy symbol: insert_length(), copy_length() yeast.c:652-693 */
+        u32 ins_new;
         {
             u64 ce = ts->cmd[sym < 704 ? sym : 0];
             u32 clo = (u32)ce, chi = (u32)(ce >> 32);
             u32 n1 = (clo >> 16) & 0xff, n2 = clo >> 24;
             u32 x1 = __builtin_amdgcn_ubfe(t, 0, n1);
             u32 x2 = __builtin_amdgcn_ubfe((u32)(t64 >> n1), 0, n2);
-            insert = dC ? (clo & 0xffff) + x1 : insert;
+            ins_new = (clo & 0xffff) + x1;
             copy = dC ? (chi & 0xffff) + x2 : copy;
             dctx = dC ? chi >> 16 : dctx;
-            implicit = dC ? (u32)(sym < 128) : implicit;
-            bo += dC ? n1 + n2 : 0;
-            left0 -= dC && switching;
-        }
-        /* ---- literal ---- */
-        const bool dL = done && st == YT_LIT;
-        if (dL)
-            gst8(op, sym);
-        op += dL;
-        p2 = dL ? p1 : p2;
-        p1 = dL ? sym : p1;
-        insert -= dL;
-        left1 -= dL && switching;
-        /* ---- distance symbol: the extra bits now, the value below ---- */
-        const bool dD = done && st == YT_DIST;
-        {
+            after = dC ? (sym < 128 ? YT_START : YT_DIST) : after; /* yeast.c:1234-1236 */
+            /* distance symbol: its extra bits now, the value under the request */
             u32 dn = sym - direct - 16;
             u32 dx = sym >= 16 + direct ? 1 + (dn >> (postfix + 1)) : 0;
             dx = dx > 24 ? 24 : dx; /* cannot be: the alphabet ends at 16 + direct + (48 << postfix) */
             dsym = dD ? sym : dsym;
             dxv = dD ? __builtin_amdgcn_ubfe(t, 0, dx) : dxv;
-            bo += dD ? dx : 0;
-            left2 -= dD && switching;
+            u32 ext = dC ? n1 + n2 : dx;
+            bo += dC || dD ? ext : 0;
         }
-        eof = eof || ((dC || dD) && bo > endrel);
-        const bool over = dC && !eof && insert > mlen; /* :1189 */
-        mlen -= dC && !eof && !over ? insert : 0;
+        insert = dC ? ins_new : insert - dL;
+        /* literal context: the bytes of a literal, or the last two bytes of the piece requested on the last trip */
         {
-            const bool bad = (active && eof) || over;
-            dry = active && eof && !rc ? 1 : dry;
-            rc = bad && !rc ? (eof ? (u32)YS_EOF : (u32)YS_INVALID) : rc;
+            u32 c1 = cxn >= 2 ? (cx >> 8) & 255 : cx & 255, c2 = cxn >= 2 ? cx & 255 : p1;
+            u32 n1 = dL ? sym : c1, n2 = dL ? p1 : c2;
+            const bool upd = dL || cxn != 0;
+            p2 = upd ? n2 : p2;
+            p1 = upd ? n1 : p1;
+            cxn = 0;
         }
+        u8 *const lit_at = op;
+        op += dL;
+        left0 -= dC && switching;
+        left1 -= dL && switching;
+        left2 -= dD && switching;
 
-        /* ---- the piece that arrived: the last two bytes written are the literal context ---- */
-        {
-            u32 k = pn >= 2 ? pn - 2 : 0, ki = k >> 2;
-            const bool k1b = ki & 1, k2b = ki & 2;
-            u32 a01 = k1b ? pv.y : pv.x, a23 = k1b ? pv.w : pv.z, b01 = k1b ? pv.z : pv.y, b23 = k1b ? 0u : pv.w;
-            u32 a = k2b ? a23 : a01, b = k2b ? b23 : b01;
-            u32 pe = __builtin_amdgcn_alignbyte(b, a, k & 3);
-            u32 n2 = pn >= 2 ? pe & 255 : p1, n1 = pn >= 2 ? (pe >> 8) & 255 : pv.x & 255;
-            p2 = pn ? n2 : p2;
-            p1 = pn ? n1 : p1;
-        }
-
-        /* ---- block switch symbols (rare) ---- */
+        /* block switch symbols (rare) */
         bool redo = false; /* the lookup of the category the switch was for */
         if (any_switching && __any(done && st >= YT_BT)) {
             const bool dT = done && st == YT_BT, dN = done && st == YT_BC;
@@ -352,20 +372,17 @@ NOINL TripOut run_trip_fn(TripIn a)
             prev3 = dT ? (prev3 & ~(255u << sh)) | (k_type << sh) : prev3;
             type3 = dT ? (type3 & ~(255u << sh)) | (n << sh) : type3;
             /* block_length(): yeast.c:550-567 */
-            u32 s = sym, base, extra;
-            if (s < 4) { base = 1 + 4 * s; extra = 2; }
-            else if (s < 8) { base = 17 + 8 * (s - 4); extra = 3; }
-            else if (s < 12) { base = 49 + 16 * (s - 8); extra = 4; }
-            else if (s < 16) { base = 113 + 32 * (s - 12); extra = 5; }
-            else if (s < 18) { base = 241 + 64 * (s - 16); extra = 6; }
-            else if (s >= 25) { base = 16625; extra = 24; }
-            else { extra = s - 11; base = 369 + ((1u << (s - 11)) - 128); }
+            u32 sb = sym, base, extra;
+            if (sb < 4) { base = 1 + 4 * sb; extra = 2; }
+            else if (sb < 8) { base = 17 + 8 * (sb - 4); extra = 3; }
+            else if (sb < 12) { base = 49 + 16 * (sb - 8); extra = 4; }
+            else if (sb < 16) { base = 113 + 32 * (sb - 12); extra = 5; }
+            else if (sb < 18) { base = 241 + 64 * (sb - 16); extra = 6; }
+            else if (sb >= 25) { base = 16625; extra = 24; }
+            else { extra = sb - 11; base = 369 + ((1u << (sb - 11)) - 128); }
             u32 cnt = base + __builtin_amdgcn_ubfe(t, 0, extra);
             bo += dN ? extra : 0;
-            const bool e2 = dN && bo > endrel;
-            dry = e2 && !rc ? 1 : dry;
-            rc = e2 && !rc ? (u32)YS_EOF : rc;
-            const bool okN = dN && !e2;
+            const bool okN = dN && bo <= endrel;
             left0 = okN && cat == YT_CMD ? cnt : left0;
             left1 = okN && cat == YT_LIT ? cnt : left1;
             left2 = okN && cat == YT_DIST ? cnt : left2;
@@ -388,58 +405,48 @@ NOINL TripOut run_trip_fn(TripIn a)
             redo = okN;
         }
         asm volatile("" : "+v"(offI), "+v"(kmode));
+        eof = eof || (active && bo > endrel);
 
-        /* ---- 2. what comes next ---- */
+        TMARK(0);
+        /* ================= 2. bytes: the copy that begins or goes on, its piece requested first of all ================= */
         /* the copy in progress ends with the piece set up on this trip */
         u32 m = crem < 16 ? crem : 16;
         m = m < cD ? m : cD;
         const bool fin = st == YT_COPY && m == crem;
-        /* category wanted by the streams that finished a symbol (or a block switch, or a copy) */
         const bool lits = insert != 0;
-        const bool after_lits = (dC || dL) && !lits; /* literals of the command done (or none) */
-        const bool ends = (dL && !lits && mlen == 0) || (fin && mlen == 0); /* :1227, :1295 */
-        const bool start = !rc && ((after_lits && !ends && implicit) || dD); /* a copy begins on this trip */
-        const bool wantL = ((dC || dL) && lits) || (redo && cat == YT_LIT);
-        const bool wantD = (after_lits && !ends && !implicit) || (redo && cat == YT_DIST);
-        const bool wantC = start || (fin && mlen != 0) || (redo && cat == YT_CMD);
-        /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
-           distance context -> table (yeast.c:1253-1257 through dt) */
-        u32 offL = offL0, offD = offD0;
-        {
-            u32 f1 = ((const LAS u8 *)ts->kctx)[(kmode + p1) * 2];
-            u32 f2 = ((const LAS u8 *)ts->kctx)[(kmode + p2) * 2 + 1];
-            u32 cid = f1 | f2;
-            u32 mi = wantD ? 64 * S + dctx * S : cid * S; /* dt lies behind lt */
-            u32 o = (u32)((const LAS u16 *)wl->lt)[mi + slot] << 4;
-            offL = ctx ? wso + o : offL;
-            offD = dmap ? wso + o : offD;
-        }
-        const bool want = (wantL || wantD || wantC) && !rc;
-        {
-            u32 w = wantL ? YT_LIT : wantD ? YT_DIST : YT_CMD;
-            u32 off_w = wantL ? offL : wantD ? offD : offI;
-            enter(want, w, off_w, left0, left1, left2);
-        }
-        st = rc || ends ? YT_END : st;
-        const bool look = st <= YT_BC && !rc;
-        request(look);
-
-        /* ---- 3. under that request: bytes ---- */
-        /* the piece loaded on the last trip: a whole unit; the excess is overwritten by what follows */
+        const bool cl = dC || dL;
+        const bool ends = (dL && !lits && mlen == 0) || (fin && mlen == 0) || eof; /* :1227, :1295 */
+        const bool to_after = cl && !lits && !ends;
+        const bool start = !rc && ((to_after && after == YT_START) || (dD && !eof)); /* a copy begins on this trip */
+        bool single = false; /* the copy that begins is one piece long and the meta-block goes on */
+        TMARK(1);
+        /* the piece loaded on the last trip (a whole unit; the excess is overwritten by what follows) and this
+           trip's literal go out before any byte is fetched: the next piece may begin with them */
         if (pn)
-            gst128u(op - pn, pv);
+            gst128u(op - dL - pn, pv);
         pn = 0;
+        TMARK(2);
+        if (dL)
+            gst8(lit_at, sym);
+        TMARK(3);
         const u32 got = (u32)(uintptr_t)op - out_lo;
+        { /* the insert length against what is left of the meta-block; end of input */
+            const bool over = dC && !eof && insert > mlen; /* :1189 */
+            mlen -= dC && !eof && !over ? insert : 0;
+            dry = active && eof && !rc ? 1 : dry;
+            rc = (active && eof) && !rc ? (u32)YS_EOF : rc;
+            rc = over && !rc ? (u32)YS_INVALID : rc;
+            st = over ? YT_END : st;
+        }
         {
-            /* distance(): yeast.c:761-789 (every lane computes it; the lanes in `start` use it) */
+            /* distance(): yeast.c:761-789 (every lane computes it; the lanes in `start` use it).  Ring buffer
+               entry and offset per symbol below 16 from packed constants: -1 +1 -2 +2 -3 +3 on the last and the
+               second-last distance */
             u32 ds = dsym;
-            u32 back = ds < 4 ? ds : (ds >= 10 ? 1u : 0u);
+            u32 back = (0x555000e4u >> (2 * (ds & 15))) & 3;
+            i32 dl = (i32)((u32)(0x6051426051423333ull >> (4 * (ds & 15))) & 15) - 3;
             u32 r01 = (back & 1) ? r1 : r0, r23 = (back & 1) ? r3 : r2;
             u32 rv = (back & 2) ? r23 : r01;
-            u32 k = ds - (ds < 10 ? 4u : 10u); /* -1 +1 -2 +2 -3 +3 */
-            i32 dl = (i32)(k >> 1) + 1;
-            dl = (k & 1) ? dl : -dl;
-            dl = ds < 4 ? 0 : dl;
             i32 dring = (i32)rv + dl;
             u32 dn = ds - direct - 16;
             u32 dx = 1 + (dn >> (postfix + 1));
@@ -482,11 +489,13 @@ NOINL TripOut run_trip_fn(TripIn a)
             u32 m2 = crem < 16 ? crem : 16;
             m2 = m2 < cD ? m2 : cD;
             m = start ? m2 : m;
-            /* the speculative request stands if the copy is one piece and the meta-block goes on */
-            u32 nst = mlen == 0 && m == crem ? YT_END : m == crem ? st : YT_COPY;
+            /* a copy of one piece costs no trip of its own: the next command's symbol is requested below */
+            u32 nst = m == crem ? (mlen == 0 ? YT_END : st) : YT_COPY;
             nst = bad ? YT_END : nst;
             st = start ? nst : st;
+            single = go && m == crem && mlen != 0;
         }
+        TMARK(4);
         /* the next piece of the copy in progress: requested now, stored on the next trip */
         {
             const bool piece = crem != 0;
@@ -504,21 +513,54 @@ NOINL TripOut run_trip_fn(TripIn a)
                     p2 = last2;
                 }
             }
-            if (piece && !tail)
-                pv = gld128u_nt(csrc); /* read once, far back in the output: not worth a place in L2 */
             m = piece ? m : 0;
+            const bool ld = piece && !tail;
+            if (ld) {
+                pv = gld128u_nt(csrc); /* read once, far back in the output: not worth a place in L2 */
+                cx = gld16u(csrc + (m >= 2 ? m - 2 : 0));
+            }
+            pn = ld ? m : 0;
+            cxn = ld ? (m >= 2 ? 2u : 1u) : 0;
             op += m;
-            pn = tail ? 0 : m;
             crem -= m;
             const bool whole = m == cD; /* a whole period is written: twice as far back is the same data */
             cD = whole ? cD * 2 : cD;
             csrc += whole ? 0 : m;
         }
+        TMARK(5);
+        /* ================= 3. what comes next, and the request for it ================= */
+        const bool wantL = (cl && lits) || (redo && cat == YT_LIT);
+        const bool wantD = (to_after && after == YT_DIST) || (redo && cat == YT_DIST);
+        const bool wantC = single || (fin && mlen != 0) || (redo && cat == YT_CMD);
+        /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
+           distance context -> table (yeast.c:1253-1257 through dt) */
+        u32 offL = offL0, offD = offD0;
+        {
+            u32 f1 = ((const LAS u8 *)ts->kctx)[(kmode + p1) * 2];
+            u32 f2 = ((const LAS u8 *)ts->kctx)[(kmode + p2) * 2 + 1];
+            u32 cid = f1 | f2;
+            u32 mi = wantD ? 64 * S + dctx * S : cid * S; /* dt lies behind lt */
+            u32 o = (u32)((const LAS u16 *)wl->lt)[mi + slot] << 4;
+            offL = ctx ? wso + o : offL;
+            offD = dmap ? wso + o : offD;
+        }
+        {
+            const bool want = (wantL || wantD || wantC) && !rc && !eof;
+            u32 w = wantL ? YT_LIT : wantD ? YT_DIST : YT_CMD;
+            u32 off_w = wantL ? offL : wantD ? offD : offI;
+            enter(want, w, off_w, left0, left1, left2);
+        }
+        st = rc || ends ? YT_END : st;
+        TMARK(6);
+        request(st <= YT_BC);
     }
 #ifdef YS_PROFILE
     if ((threadIdx.x & 63) == 0 && cap >= 128) { /* the profile build's output bytes are not meant to be looked at */
         u64 *prof = (u64 *)(a.out + cap - 128);
         prof[12] = ntrip;
+        prof[2] = pwait;
+        for (int i = 0; i < 8; i++)
+            prof[3 + i] = pt[i];
         prof[13] = t_loop - a.t_start;
         prof[14] = __builtin_amdgcn_s_memrealtime() - t_loop;
     }

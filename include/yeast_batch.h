@@ -65,6 +65,9 @@ int yeast_batch(size_t n, void const *const *src, size_t *len, void **dest, size
  *              (cooperative kernel: that many lanes of a wavefront cooperate on one stream); 65 = one wavefront
  *              per stream with the stream's prefix-code tables in LDS (lowest latency; the default below
  *              8,192 streams, 1 from there on)
+ * Calls on one device share the library's per-device counters and table workspaces: a call on another stream
+ * than the last one first waits (on the device, through an event) for the last call's kernels, so batches never
+ * overlap on one device whatever streams they are given to; calls from several host threads are serialised.
  * Returns 0 or a negative error (see yeast_last_error()).
  */
 int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, void *d_dst, const uint64_t *d_dst_off,
@@ -81,12 +84,15 @@ int yeast_check_device(const void *d_dst, const uint64_t *d_dst_off, yeast_recor
  *   crc32c()  replaces crc32c.h:13 / crc32c.c:258 (chainable through crc)
  *   XXH32()   replaces xxhash.h XXH32  (xxhash.c:365)
  *   XXH64()   replaces xxhash.h XXH64  (xxhash.c:505)
- * On a GPU failure they write a message to stderr and abort(): there is no
- * in-band error value in these signatures.
+ * There is no in-band error value in these signatures: on a GPU failure they write a message to stderr,
+ * return 0 and count the failure; yeast_check_error() returns (and clears) the calling thread's count, so a
+ * caller that must tell a check of 0 from a failure asks it after the call (the digest functions of the
+ * streaming forms below do the same).  The host process is never aborted.
  */
 uint32_t crc32c(uint32_t crc, void const *buf, size_t len);
 unsigned int XXH32(const void *input, size_t len, unsigned int seed);
 unsigned long long XXH64(const void *input, size_t len, unsigned long long seed);
+int yeast_check_error(void); /* check-value calls of this thread that failed since the last call of this; 0 = none */
 
 /*
  * The streaming forms of the two hashes (xxhash.h:139-167, xxhash.c:588-960), which broad.c:31-62,121-122
@@ -115,6 +121,10 @@ unsigned long long XXH64_digest(const XXH64_state_t *state);
    counterpart in the reference, whose yeast() keeps nothing between calls; for long-running hosts after
    an unusually large batch.  Waits for the device's outstanding work; 0 on success. */
 int yeast_trim(void);
+
+/* The YEAST_* environment knobs (measurement and test aids: INTEGRATION.md) are read when the library is first
+   used, never on the path of a call; this reads them again.  No counterpart in the reference. */
+void yeast_reload_knobs(void);
 
 /* Diagnostics. */
 const char *yeast_last_error(void);   /* thread-local text of the last failure, "" if none */

@@ -61,6 +61,17 @@ def test_testdata_corpus_compare_mode():
 KERNELS = [64, 65, 1]  # cooperative, wavefront per stream (LDS tables), one stream per lane
 
 
+def test_compare_mode_against_the_reference_fixtures():
+    # SURVEY 8c "cmp mode mismatch positions": (rc, got, used) of the real reference's yeast(cmp=1)
+    from test_oracle_golden import cmp_cases
+    n = 0
+    for c, comp, expected in cmp_cases():
+        rc, got, used, _ = gpu_yeast(comp, expected)
+        assert (rc, got, used) == (c["rc"], c["got"], c["used"]), c
+        n += 1
+    assert n > 400
+
+
 @pytest.mark.parametrize("lanes", KERNELS)
 def test_crafted_streams_through_every_kernel(lanes, monkeypatch):
     monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
@@ -233,6 +244,92 @@ def test_full_size_batch_properties():
     assert (r["check"] == want).all()
 
 
+def test_shard_count_invariance():
+    # the batch cut into N contiguous shards balanced by compressed bytes gives, shard
+    # after shard, exactly the records and the bytes of the uncut batch (every stream is independent:
+    # yeast.c:1315-1336 resets all state per call)
+    import torch
+    from brotli_amd.device import DeviceBatch
+    from brotli_amd.sharding import balanced_shards
+    meta, distinct = H.packed_streams("cfg2_streams")
+    n = 16384
+    order = np.random.RandomState(5).randint(0, len(distinct), size=n)
+    streams = [distinct[j] for j in order]
+    whole = DeviceBatch(streams, [65536] * n)
+    whole.decode(check=ba.CHECK_XXH64)
+    torch.cuda.synchronize()
+    want = whole.records()
+    assert (want["rc"] == 0).all()
+    want_bytes = whole.dst[:n * 65536].cpu().numpy()
+    for shards in (2, 4, 8):
+        cuts = balanced_shards([len(s) for s in streams], shards)
+        recs, outs = [], []
+        for lo, hi in cuts:
+            part = DeviceBatch(streams[lo:hi], [65536] * (hi - lo))
+            part.decode(check=ba.CHECK_XXH64)
+            torch.cuda.synchronize()
+            recs.append(part.records())
+            outs.append(part.dst[:(hi - lo) * 65536].cpu().numpy())
+        assert np.concatenate(recs).tobytes() == want.tobytes(), shards
+        assert np.array_equal(np.concatenate(outs), want_bytes), shards
+
+
+def test_two_batches_in_flight_on_two_streams():
+    # every call on a device shares the library's counters and table workspaces: a batch enqueued on another
+    # stream must wait for the one before it (include/yeast_batch.h)
+    import torch
+    from brotli_amd.device import DeviceBatch
+    meta, distinct = H.packed_streams("cfg2_streams")
+    a = DeviceBatch([distinct[j % 256] for j in range(9000)], [65536] * 9000)
+    b = DeviceBatch([distinct[(7 * j + 3) % 256] for j in range(8500)], [65536] * 8500)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            a.decode(check=ba.CHECK_XXH64)
+        with torch.cuda.stream(s2):
+            b.decode(check=ba.CHECK_XXH64)
+    torch.cuda.synchronize()
+    for batch, f in ((a, lambda j: j % 256), (b, lambda j: (7 * j + 3) % 256)):
+        r = batch.records()
+        assert (r["rc"] == 0).all() and (r["got"] == 65536).all()
+        for j in range(batch.n):
+            assert "%016x" % int(r["check"][j]) == meta["streams"][f(j)]["xxh64"], j
+
+
+def test_entry_points_from_many_host_threads():
+    # SURVEY 8b Threading: yeast() keeps no global state (try.h:353-361), so callers may call it from many
+    # threads at once; here eight threads call yeast(), yeast_batch() and the check functions together
+    import threading
+    meta, distinct = H.packed_streams("cfg2_streams")
+    idx = H.load_json("testdata.json")
+    pairs = list(H.testdata_pairs())
+    errors = []
+
+    def work(t):
+        try:
+            rnd = random.Random(t)
+            for rep in range(6):
+                name, comp, orig = pairs[rnd.randrange(len(pairs))]
+                rc, out, got, used = ba.yeast(comp)
+                assert (rc, out) == (0, orig), name
+                rc, _, got, used = ba.yeast(comp, orig)
+                assert (rc, got, used) == (0, len(orig), idx[name]["used"]), name
+                pick = [rnd.randrange(256) for _ in range(40)]
+                res = ba.yeast_batch([distinct[j] for j in pick], ba.CHECK_CRC32C)
+                for j, r in zip(pick, res):
+                    assert (r[0], r[2]) == (0, 65536) and "%08x" % r[4] == meta["streams"][j]["crc32c"]
+                assert "%016x" % ba.xxh64(orig) == idx[name]["xxh64"] if "xxh64" in idx[name] else True
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert ba.lib().yeast_check_error() == 0
+
+
 def test_device_api_reports_small_output_region():
     from brotli_amd.device import DeviceBatch
     import torch
@@ -334,6 +431,52 @@ def test_br_writer_and_merger_byte_exact():
     # what is written here reads back through the reader
     rc, b = ba.brand(cfg2[3], "c2u")
     assert ba.broad(b) == (0, H.oracle_yeast(cfg2[3])[3], 1)
+
+
+def test_merger_survives_wild_reverse_offsets():
+    # braid.c:182,195 subtract whatever distance the file gives from an off_t: 2^63 and more moves the offset
+    # forward, more than the offset makes it negative.  Reading there is end of file (status 1, file skipped)
+    # or "invalid distance" in the reference; here it must never leave the buffer.
+    def par(n):
+        return (0x34cb00 >> ((n ^ (n >> 4)) & 0xf)) & 0x80
+
+    def bvar(n):
+        out = [0x80 | (n & 0x7f)]
+        n >>= 7
+        while n > 0x7f:
+            out.append(n & 0x7f)
+            n >>= 7
+        out.append(0x80 | n)
+        return bytes(out)
+
+    def var(n):
+        out = []
+        while n > 0x7f:
+            out.append(n & 0x7f)
+            n >>= 7
+        out.append(0x80 | n)
+        return bytes(out)
+    sig = bytes([0xce, 0xb2, 0xcf, 0x81])
+    trail = 0x20 | 0x10 | 7
+    trail ^= par(trail)
+    rc, good = ba.brand(open(os.path.join(H.GOLD, "testdata", "quickfox.compressed"), "rb").read(), "")
+    assert rc == 0
+    empty = ba.braid([])
+    wild = []
+    for dist in ((1 << 63) + 5, (1 << 64) - 1, 10 ** 6, (1 << 63), 3):
+        wild.append(sig + bytes(40) + bytes([trail]) + bvar(dist) + bytes([trail]))
+    # a header whose own reverse offset is wild: header mask with an offset, reached from a sane trailer
+    hm = 0x10 | 7
+    hm ^= par(hm)
+    for back in ((1 << 63) + 1, (1 << 64) - 3, 1 << 40):
+        body = sig + bytes(8) + bytes([hm]) + var(back) + bytes([0]) + bytes(20)
+        dist = len(body) - 12
+        wild.append(body + bytes([trail]) + bvar(dist) + bytes([trail]))
+    for w in wild:
+        assert ba.braid([w]) == (1, empty[1]), w.hex()
+        assert ba.braid([good, w, good])[0] == 1
+        assert ba.braid([good, w, good])[1] == ba.braid([good, good])[1]
+        assert ba.broad(w)[0] != 0
 
 
 def test_streaming_hashes_any_chunking():

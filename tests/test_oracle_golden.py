@@ -163,3 +163,41 @@ def test_brogen_counterpart_writes_the_reference_streams():
             assert got[0] == 2, name
         if ref is not None:
             assert H.run_yeast(ref.yeast, stream) == got, name
+
+
+def _cmp_sources():
+    src = {}
+    for name, comp, orig in H.testdata_pairs():
+        src["testdata/" + name] = (comp, orig)
+    for fixture, tag in (("cfg2_streams", "cfg2"), ("misc_streams", "misc")):
+        meta, streams = H.packed_streams(fixture)
+        for i, s in enumerate(streams):
+            src["%s/%d" % (tag, i)] = (s, None)
+    return src
+
+
+def cmp_cases():
+    """tests/golden/cmp_cases.json: (case, compressed stream, expected data handed to yeast(cmp=1))."""
+    import sys
+    sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+    from make_cmp_fixtures import expected_of
+    src = _cmp_sources()
+    decoded = {}
+    for c in H.load_json("cmp_cases.json")["cases"]:
+        comp, orig = src[c["stream"]]
+        if orig is None:
+            if c["stream"] not in decoded:
+                decoded[c["stream"]] = H.oracle_yeast(comp)[3]
+            orig = decoded[c["stream"]]
+        yield c, comp, expected_of(orig, c)
+
+
+def test_compare_mode_against_the_reference_fixtures():
+    # what the real reference's yeast(cmp=1) returns at a mismatch, for short and for long expected data
+    # (yeast.c:1042-1045, 1216-1219, 1270-1273, 1286-1289; tools/make_cmp_fixtures.py)
+    n = 0
+    for c, comp, expected in cmp_cases():
+        rc, got, used, _ = H.oracle_yeast(comp, expected)
+        assert (rc, got, used) == (c["rc"], c["got"], c["used"]), c
+        n += 1
+    assert n > 400

@@ -24,12 +24,12 @@ rows = []
 for i in range(0, n, S):
     e = int(offs[i + 1])
     rows.append(host[e - 128:e - 128 + 120].view(np.uint64).astype(np.float64))
-m = np.stack(rows).mean(0)
-names = ["block switch", "A issue (piece loads, lookup)", "A wait", "A store piece + command", "B issue", "B wait", "B literal", "C issue",
-         "C wait", "C distance", "D copy set-up", "loop head"]
-order_ = [11, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
-tot = m[:12].sum()
-print("passes per wavefront %.0f; cycles per pass %.0f" % (m[12], tot / m[12]))
-print("header and tables %.2f ms, loop %.2f ms per wavefront (mean); slowest loop %.2f ms; clock in the loop %.2f GHz" % (m[13] / 1e5, m[14] / 1e5, np.stack(rows)[:, 14].max() / 1e5, tot / (m[14] * 10)))
-for k in order_:
-    print("  %-34s %8.0f cycles/pass  %5.1f%%" % (names[k], m[k] / m[12], 100 * m[k] / tot))
+A = np.stack(rows)
+m = A.mean(0)
+# prof[12] = trips of the wavefront, [13] = header and tables, [14] = the loop (both in 10 ns units)
+print("trips per wavefront: mean %.0f max %.0f" % (m[12], A[:, 12].max()))
+print("header and tables %.2f ms, loop %.2f ms per wavefront (mean); slowest loop %.2f ms" % (m[13] / 1e5, m[14] / 1e5, A[:, 14].max() / 1e5))
+print("time per trip: %.0f ns" % (10 * m[14] / m[12]))
+print("cycles per trip: waiting at the head %.0f" % (m[2] / m[12]))
+for k, name in enumerate(["1 consume, block switch", "flags", "store of the last piece", "store of the literal", "mlen, distance, dictionary, copy set-up", "piece request", "3 next: states, context, enter", "request, loop back, wait"]):
+    print("  %-44s %6.0f" % (name, m[3 + k] / m[12]))
