@@ -83,6 +83,10 @@ def lib() -> ctypes.CDLL:
         L.yeast_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int,
                                          ctypes.c_void_p]
+        L.yeast_batch_device_static.restype = ctypes.c_int
+        L.yeast_batch_device_static.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p]
+        L.yeast_init.restype = ctypes.c_int
         L.yeast_check_device.restype = ctypes.c_int
         L.yeast_check_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                          ctypes.c_uint, ctypes.c_void_p]

@@ -77,3 +77,56 @@ extern "C" int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cm
     }
     return -1;
 }
+
+/* ---------------------------------------------------------------- the entry point that allocates nothing
+ * yeast_batch_device_static() (include/yeast_batch.h) decodes with the cooperative kernel, one wavefront per
+ * stream, on YS_STATIC_GROUPS resident wavefronts whose workspace slots -- worst-case size each, so no stream
+ * ever needs the retry pass -- lie in this array instead of in memory the library allocates.  The array's name
+ * is a host-side stand-in: the device address is asked for once per device (ys_static_init) and used from
+ * then on.  Layout: 256 bytes of counters, the retry list (never filled: see above), the slots.
+ */
+#define YS_STATIC_GROUPS 16
+#define YS_STATIC_MAX_STREAMS 16384
+#define YS_STATIC_SLOT ((YS_WS_MAX + 255) & ~(size_t)255)
+#define YS_STATIC_LIST (256 + (size_t)YS_STATIC_MAX_STREAMS * 4)
+static __device__ __align__(256) unsigned char scratch[YS_STATIC_LIST + YS_STATIC_GROUPS * YS_STATIC_SLOT];
+static unsigned char *g_scratch_ptr[64]; /* per device: each GPU holds its own copy of the array */
+
+extern "C" int ys_static_init(int device)
+{
+    if (device < 0 || device >= 64)
+        return -1;
+    if (g_scratch_ptr[device])
+        return 0;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+        return e != hipSuccess ? (int)e : -1;
+    g_scratch_ptr[device] = (unsigned char *)ptr;
+    return 0;
+}
+extern "C" unsigned ys_static_max_streams(void) { return YS_STATIC_MAX_STREAMS; }
+extern "C" size_t ys_static_bytes(void) { return sizeof(scratch); }
+
+/* p: everything but the workspace and the counters filled in by the caller; n <= YS_STATIC_MAX_STREAMS */
+extern "C" int ys_launch_decode_static(const ys_params *p_in, int device, void *stream)
+{
+    if (device < 0 || device >= 64 || !g_scratch_ptr[device])
+        return -1;
+    unsigned char *ptr = g_scratch_ptr[device];
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ptr, 0, 256, st); /* the counters start at zero; the slots need no clearing */
+    if (e != hipSuccess)
+        return (int)e;
+    ys_params p = *p_in;
+    p.counter = (u32 *)ptr;
+    p.retry_count = (u32 *)ptr + 2;
+    p.retry_list = (u32 *)(ptr + 256);
+    p.retry = 0;
+    p.order = nullptr;
+    p.debug = 0;
+    p.rootcaps = 0;
+    p.ws = ptr + YS_STATIC_LIST;
+    p.ws_stride = YS_STATIC_SLOT;
+    return launch_decode_t<64, false>(p, YS_STATIC_GROUPS, st);
+}

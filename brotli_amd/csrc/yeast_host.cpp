@@ -28,6 +28,10 @@ extern const unsigned char ys_transforms[2420];
 int ys_upload_constants(const u8 *lut768);
 int ys_upload_check_constants(const u32 *x2n);
 int ys_launch_decode(const ys_params *p, int lanes_per_stream, int cmp, unsigned groups, void *stream);
+int ys_static_init(int device);
+unsigned ys_static_max_streams(void);
+size_t ys_static_bytes(void);
+int ys_launch_decode_static(const ys_params *p, int device, void *stream);
 int ysl_upload_constants(const u8 *lut768);
 int ysl_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base, u8 *xdict, void *stream);
 int ysl_launch(const ys_params *p, int half, unsigned streams, void *stream);
@@ -237,6 +241,10 @@ static int device_get(Device **out)
         hipDeviceProp_t prop;
         HIPCK(hipGetDeviceProperties(&prop, id));
         d.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        e = ys_static_init(id); /* the address of the static workspace of yeast_batch_device_static() */
+        if (e)
+            return fail("static workspace address", (hipError_t)e);
+        HIPCK(hipEventCreateWithFlags(&d.last_ev, hipEventDisableTiming));
         d.ready = true;
     }
     *out = &d;
@@ -342,8 +350,6 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     }
     /* Every call on a device shares its counters and table workspaces: a call on another stream waits for the
        last one's kernels (calls on one stream are ordered anyway). */
-    if (!d.last_ev)
-        HIPCK(hipEventCreateWithFlags(&d.last_ev, hipEventDisableTiming));
     if (d.have_ev && d.last_st != st)
         HIPCK(hipStreamWaitEvent(st, d.last_ev, 0));
     struct Mark { /* whatever the way out, later calls wait for what this one has enqueued */
@@ -500,6 +506,66 @@ extern "C" int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, 
     }
     return enqueue(*d, (const u8 *)d_src, d_src_off, (u8 *)d_dst, d_dst_off, (ys_record *)d_rec, n, check_kind,
                    lanes_per_stream, 0, (hipStream_t)hip_stream);
+}
+
+extern "C" int yeast_init(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Device *d;
+    return device_get(&d) ? -1 : 0;
+}
+
+/* The same decode and check as yeast_batch_device(), for callers that cannot allocate: nothing here calls
+   hipMalloc, hipFree or anything that does (the device must have been set up by yeast_init() or an earlier call
+   of any other entry point, which may allocate).  The kernels' workspace is a static device array. */
+extern "C" int yeast_batch_device_static(const void *d_src, const uint64_t *d_src_off, void *d_dst,
+                                         const uint64_t *d_dst_off, yeast_record *d_rec, size_t n,
+                                         unsigned check_kind, void *hip_stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int id = 0;
+    HIPCK(hipGetDevice(&id));
+    if (id < 0 || id >= 64 || !g_dev[id].ready) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: yeast_batch_device_static() before yeast_init() on this device");
+        return -1;
+    }
+    if (check_kind > 3) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: unknown check kind %u", check_kind);
+        return -1;
+    }
+    if (n > ys_static_max_streams()) {
+        snprintf(t_err, sizeof(t_err), "libyeast_mi355x: yeast_batch_device_static() takes at most %u streams per call (%zu asked for)",
+                 ys_static_max_streams(), n);
+        return -1;
+    }
+    if (n == 0)
+        return 0;
+    Device &d = g_dev[id];
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (d.have_ev && d.last_st != st) /* calls on one device share the static workspace too */
+        HIPCK(hipStreamWaitEvent(st, d.last_ev, 0));
+    ys_params p;
+    memset(&p, 0, sizeof(p));
+    p.src = (const u8 *)d_src;
+    p.src_off = d_src_off;
+    p.dst = (u8 *)d_dst;
+    p.dst_off = d_dst_off;
+    p.rec = (ys_record *)d_rec;
+    p.n = (u32)n;
+    p.dict = d.d_dict;
+    p.xforms = d.d_xf;
+    p.xdict = d.d_xdict;
+    p.xdict_base = d.d_xbase;
+    int e = ys_launch_decode_static(&p, id, st);
+    if (!e && check_kind)
+        e = ys_launch_check((const u8 *)d_dst, d_dst_off, (ys_record *)d_rec, (unsigned)n, check_kind, 0, st);
+    if (hipEventRecord(d.last_ev, st) == hipSuccess) {
+        d.last_st = st;
+        d.have_ev = true;
+    }
+    if (e)
+        return fail("static decode launch", (hipError_t)e);
+    return 0;
 }
 
 extern "C" int yeast_check_device(const void *d_dst, const uint64_t *d_dst_off, yeast_record *d_rec, size_t n,

@@ -58,6 +58,14 @@ class DeviceBatch:
         if e:
             raise _err("yeast_batch_device")
 
+    def decode_static(self, check: int = CHECK_NONE):
+        """The same through yeast_batch_device_static(): the entry point that allocates nothing."""
+        st = self.torch.cuda.current_stream().cuda_stream
+        e = lib().yeast_batch_device_static(self.src.data_ptr(), self.src_off.data_ptr(), self.dst.data_ptr(),
+                                            self.dst_off.data_ptr(), self.rec.data_ptr(), self.n, check, st)
+        if e:
+            raise _err("yeast_batch_device_static")
+
     def check(self, kind: int):
         st = self.torch.cuda.current_stream().cuda_stream
         e = lib().yeast_check_device(self.dst.data_ptr(), self.dst_off.data_ptr(), self.rec.data_ptr(), self.n,

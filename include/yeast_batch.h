@@ -74,6 +74,26 @@ int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, void *d_dst
                        yeast_record *d_rec, size_t n, unsigned check_kind, int lanes_per_stream,
                        void *hip_stream);
 
+/*
+ * yeast_batch_device() for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same records, same output
+ * bytes; the call makes no allocation of any kind (device, pinned or through a library): the decode kernels'
+ * workspace -- counters and the table arenas of the resident wavefronts, which the other entry points allocate
+ * -- is a static device array of 29 MB that each GPU the library runs on holds until the process ends.
+ *   - the device must have been set up before, by yeast_init() (which allocates the dictionary tables once
+ *     per device) or by any earlier call of another entry point; otherwise the call fails with -1;
+ *   - at most 16,384 streams per call; more is refused with -1 and a message (yeast_last_error());
+ *   - sixteen wavefronts decode (one stream each at a time, worst-case table arenas, so every valid stream
+ *     decodes): meant for modest batches, not for throughput;
+ *   - every call on a GPU uses that GPU's one array: the library orders its own calls on a device one after the
+ *     other (across streams too), but two processes' or two libraries' kernels are not its business, and a
+ *     captured graph that holds this call must not be replayed while another call of the library runs on the
+ *     same GPU.
+ */
+int yeast_init(void); /* set up the current device (allocates its constant tables once); 0 or -1 */
+int yeast_batch_device_static(const void *d_src, const uint64_t *d_src_off, void *d_dst, const uint64_t *d_dst_off,
+                              yeast_record *d_rec, size_t n, unsigned check_kind, void *hip_stream);
+
 /* Check values only, over outputs already in device memory: fills
    d_rec[i].check from d_dst[d_dst_off[i] .. +d_rec[i].got). */
 int yeast_check_device(const void *d_dst, const uint64_t *d_dst_off, yeast_record *d_rec, size_t n,
