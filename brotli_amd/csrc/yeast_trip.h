@@ -78,6 +78,11 @@ DEV void trip_shared_fill(TripShared &ts, const u8 *xforms, const u32 *xbase)
 DEV u32 sld16(const u8 *base, u32 off) { return *(const GAS u16 *)(base + (u64)off); }
 DEV u32 sld32(const u8 *base, u32 off) { return *(const GAS u32 *)(base + (u64)off); }
 DEV u32 sld8(const u8 *base, u32 off) { return *(const GAS u8 *)(base + (u64)off); }
+DEV u32x4 sld128(const u8 *base, u32 off) /* 4-byte aligned */
+{
+    typedef u32x4 __attribute__((aligned(4))) u32x4a;
+    return *(const GAS u32x4a *)(base + (u64)off);
+}
 
 #define YT_CMD 0u
 #define YT_LIT 1u
@@ -132,10 +137,17 @@ NOINL TripOut run_trip_fn(TripIn a)
 
     /* ---- per-type tables of the current block types ---- */
     const u32 w_ltab = a.w_ltab;
-    auto load_lt = [&](u32 type) {
+    auto load_lt = [&](u32 type) { /* 64 offsets, sixteen per round of loads */
 #pragma clang loop unroll(disable)
-        for (u32 n = 0; n < 64; n++)
-            wl->lt[n * S + slot] = (u16)(sld32(wsb, w_ltab + ((type << 6) + n) * 4) >> 4);
+        for (u32 n = 0; n < 64; n += 16) {
+            const u32 at = w_ltab + ((type << 6) + n) * 4;
+            u32x4 v0 = sld128(wsb, at), v1 = sld128(wsb, at + 16), v2 = sld128(wsb, at + 32), v3 = sld128(wsb, at + 48);
+            LAS u16 *to = &wl->lt[n * S + slot];
+            to[0 * S] = (u16)(v0.x >> 4); to[1 * S] = (u16)(v0.y >> 4); to[2 * S] = (u16)(v0.z >> 4); to[3 * S] = (u16)(v0.w >> 4);
+            to[4 * S] = (u16)(v1.x >> 4); to[5 * S] = (u16)(v1.y >> 4); to[6 * S] = (u16)(v1.z >> 4); to[7 * S] = (u16)(v1.w >> 4);
+            to[8 * S] = (u16)(v2.x >> 4); to[9 * S] = (u16)(v2.y >> 4); to[10 * S] = (u16)(v2.z >> 4); to[11 * S] = (u16)(v2.w >> 4);
+            to[12 * S] = (u16)(v3.x >> 4); to[13 * S] = (u16)(v3.y >> 4); to[14 * S] = (u16)(v3.z >> 4); to[15 * S] = (u16)(v3.w >> 4);
+        }
     };
     auto load_dt = [&](u32 type) {
 #pragma clang loop unroll(disable)
