@@ -11,6 +11,13 @@ bytes (English text, brotli quality 11, lgwin 22), tiled from the 256 distinct c
 tests/golden/cfg2_streams.bin in a fixed pseudo-random order.  Scaling is weak: every rank decodes
 its own 65,536-stream shard; value = bytes decoded by all ranks / max-over-ranks time.
 
+--scaling strong (BASELINE.json config 3, "same batch sharded"): ONE batch of --streams streams for the
+whole job, cut into contiguous shards by compressed bytes (brotli_amd.sharding.balanced_shards), one
+per rank; the records are all-gathered, value = bytes of the whole batch / max-over-ranks time.  The
+line then carries "strong_scaling_floor": the single-GPU kernel time over batch sizes
+(profiles/r02/stream_series.json), i.e. what a shard of that size costs -- a launch lasts as long as
+its longest stream, so a shard of 8,192 streams is not 8 x faster than the batch of 65,536.
+
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through
 python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
@@ -87,6 +94,34 @@ def cpu_baseline(streams, order, cores, sample):
                       % (sample, total, cores)}
 
 
+def measured_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
+    """HBM-to-HBM copy rate on this GPU (bytes read + bytes written per second), the practical
+    ceiling beside the 8 TB/s spec figure (SURVEY 8d side figure)."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def kernel_label(n, lanes):
+    """The decode kernel the library's dispatcher picks (yeast_host.cpp enqueue())."""
+    env = int(os.environ.get("YEAST_LANES", "0"))
+    lanes = lanes or env or (1 if n >= 8192 else 65)
+    if lanes == 65:
+        return "k_decode_wave"
+    if lanes == 1:
+        half = int(os.environ.get("YEAST_HALF", "0" if n >= 131072 else "1"))
+        return "k_decode_lean<%d>" % {0: 64, 1: 32, 2: 16}.get(half, 32)
+    return "k_decode<%d>" % lanes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +133,8 @@ def main():
     ap.add_argument("--order", default="shuffled", choices=["shuffled", "wave", "same"],
                     help="diagnostic stream layouts (see build_order); the metric is quoted on shuffled")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="streams for the host baseline (0 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --streams per GPU; strong: --streams for the whole job, sharded over the ranks")
     args = ap.parse_args()
 
     import torch
@@ -118,8 +155,21 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     meta, distinct = load_distinct()
-    n = args.streams
-    order = build_order(n, len(distinct), 0x5EED + rank, args.order)
+    strong = args.scaling == "strong"
+    sizes = None
+    if strong:
+        # one batch for the whole job (the same on every rank), this rank's contiguous shard of it
+        from brotli_amd.sharding import balanced_shards
+        full = build_order(args.streams, len(distinct), 0x5EED, args.order)
+        shards = balanced_shards([len(distinct[j]) for j in full], world)
+        lo, hi = shards[rank]
+        order = full[lo:hi]
+        sizes = [(b - a) * 32 for a, b in shards]
+        if hi == lo:
+            raise SystemExit("bench: fewer streams than ranks")
+    else:
+        order = build_order(args.streams, len(distinct), 0x5EED + rank, args.order)
+    n = len(order)
     streams = [distinct[j] for j in order]
     batch = DeviceBatch(streams, [65536] * n, device=dev)
     want_got = np.array([meta[j]["got"] for j in order], dtype=np.uint64)
@@ -131,7 +181,7 @@ def main():
     def step():
         batch.decode(check=args.check, lanes=args.lanes)
         if dist is not None:
-            return all_gather_records(batch.rec, dist)
+            return all_gather_records(batch.rec, dist, sizes=sizes)
         return batch.rec
 
     def barrier():
@@ -147,7 +197,7 @@ def main():
     if args.check:
         ok = ok and (r["check"] == want_chk).all()
     if not ok:
-        bad = int(np.argmax((r["rc"] != 0) | (r["got"] != want_got) | (r["check"] != want_chk)))
+        bad = int(np.argmax((r["rc"] != 0) | (r["got"] != want_got) | (r["used"] != want_used) | ((r["check"] != want_chk) & bool(args.check))))
         raise SystemExit("bench: decode results do not match the fixtures (first bad stream %d: %s)" % (bad, r[bad]))
 
     barrier()
@@ -187,7 +237,12 @@ def main():
     in_bytes = float(want_used.sum())
     algo = out_bytes + in_bytes  # B = used_in + got_out per stream
     ms_per_step = dt / args.steps * 1e3
-    value = out_bytes * world / (dt / args.steps) / 1e9
+    if strong:  # the whole batch's bytes: every rank knows the batch
+        job_out = float(sum(meta[j]["got"] for j in full))
+    else:
+        job_out = out_bytes * world
+    value = job_out / (dt / args.steps) / 1e9
+    copy_gbs = measured_copy_gbs(torch, dev) if rank == 0 else None
     achieved = algo / (k_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/prof_summary.py from the PMC passes
@@ -202,22 +257,37 @@ def main():
     line = {
         "metric": "decompressed GB/s (whole node), batched 64 KiB brotli streams",
         "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "cfg2: %d streams/GPU x 65,536 B out, q11 lgwin22 English text, %d distinct "
+        "config": {"workload": "cfg2: %s x 65,536 B out, q11 lgwin22 English text, %d distinct "
                                "streams tiled in seeded order; decode + %s check%s"
-                               % (n, len(distinct), {0: "no", 1: "CRC-32C", 2: "XXH32", 3: "XXH64"}[args.check],
+                               % ("%d streams in all, sharded by compressed bytes over %d GPU(s)" % (args.streams, world)
+                                  if strong else "%d streams/GPU" % n,
+                                  len(distinct), {0: "no", 1: "CRC-32C", 2: "XXH32", 3: "XXH64"}[args.check],
                                   " + RCCL all-gather of records" if world > 1 else ""),
                    "streams_per_gpu": n, "order": args.order, "out_bytes_per_gpu": out_bytes, "in_bytes_per_gpu": in_bytes,
-                   "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "1")),
+                   "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "0")) or (1 if n >= 8192 else 65),
                    "parallelism": "%d independent shards" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_decode_lean<32>" if n >= 16384 and not args.lanes else "k_decode*", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": kernel_label(n, args.lanes), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": algo, "kernel_ms": k_ms, "check_kernel_ms": c_ms},
+                     "algorithmic_bytes_per_launch": algo, "kernel_ms": k_ms, "check_kernel_ms": c_ms,
+                     "measured_copy_GBs": copy_gbs,
+                     "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None},
     }
+    series = os.path.join(ROOT, "profiles", "r02", "stream_series.json")
+    if os.path.exists(series):
+        # single-GPU kernel time over batch sizes: what one shard of a strong-scaling run costs
+        line["strong_scaling_floor"] = json.load(open(series))
     if rank == 0 and world == 1 and args.cpu_sample:
-        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-        line["cpu_baseline"] = cpu_baseline(distinct, order, cores, min(args.cpu_sample, max(n, 256)))
+        # threads: this job's CPU share (OMP_NUM_THREADS is set to it on the GPU box, where os.cpu_count()
+        # counts the whole machine); host_cpus says what the machine has
+        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or share
+        sample = min(args.cpu_sample, max(n, 256))
+        line["cpu_baseline"] = cpu_baseline(distinct, order, cores, sample)
+        line["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        line["cpu_baseline"]["cpu_share"] = share
+        line["cpu_baseline_1thread"] = cpu_baseline(distinct, order, 1, max(256, sample // 16))
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -250,6 +250,8 @@ struct Decoded {
     uint64_t check; /* of the batch kind that belongs to the header's check (none for SHA-256) */
     bool have_sha;
     uint8_t sha[32];
+    unsigned kind; /* the batch kind it was decoded ahead with (the header the backward index parsed) */
+    bool fetched;  /* data holds the decoded bytes (else they stayed on the device) */
 };
 
 } // namespace
@@ -336,6 +338,8 @@ extern "C" int yeast_broad(const void *br, size_t len, void **out, size_t *out_l
                 d.used = ln[i];
                 d.check = chk[i];
                 d.have_sha = false;
+                d.kind = kind;
+                d.fetched = fetch;
                 ready[plan[pick[i]].stream] = d;
                 if (kind == YEAST_CHECK_NONE && rc[i] == 0) {
                     sbuf.push_back(dest[i]);
@@ -385,10 +389,18 @@ extern "C" int yeast_broad(const void *br, size_t len, void **out, size_t *out_l
             /* the stream: decoded ahead, or now */
             Decoded d;
             auto it = ready.find(c.next);
+            bool ahead = false;
             if (it != ready.end()) {
+                /* only for the header it was decoded for: the walk may reach the same stream offset through
+                   another header (one that begins inside the indexed header's name or extra field), whose
+                   check is of another kind; then the stream is decoded here like any that was not indexed */
                 d = it->second;
                 ready.erase(it);
-            } else {
+                ahead = d.kind == batch_kind(h.mask) && (d.fetched || !write);
+                if (!ahead)
+                    free(d.data);
+            }
+            if (!ahead) {
                 d.data = nullptr;
                 d.got = 0;
                 d.used = len - c.next;

@@ -74,6 +74,9 @@ typedef struct {
 #define YS_WS_DDIR 9088     /* u32[256]  byte offset of each distance table (header only) */
 #define YS_WS_ARENA 10240   /* block-switch tables, literal context map, literal table map, code tables */
 /* worst case: 16 KiB literal map + 64 KiB literal table map + 774 tables of at most 1,104 u16 entries */
+/* output bytes up to which the batch kernel (one stream per lane) keeps a stream; longer ones are handed to the
+   retry pass (one wavefront per stream, wide copies) */
+#define YS_LANE_MAX_OUT (1ull << 20)
 #define YS_WS_MAX (YS_WS_ARENA + 16384 + 65536 + 774 * 2208 + 4096)
 
 #endif

@@ -34,9 +34,11 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
     u32 lane = threadIdx.x;
     u32 wave = (blockIdx.x * blockDim.x + lane) >> 6;
     u32 slot = lane & 63;
-    u8 *ws = p.ws + (u64)(wave * S + (slot < S ? slot : 0)) * p.ws_stride;
+    /* the wavefront's workspaces: tables are addressed from wbase with 32-bit offsets (S * ws_stride <= 64 MiB) */
+    u8 *const wbase = p.ws + (u64)(wave * S) * p.ws_stride;
+    u8 *ws = wbase + (u64)(slot < S ? slot : 0) * p.ws_stride;
     if (p.debug & 1) /* every stream of the wavefront uses one workspace: only meaningful when they are copies of one stream */
-        ws = p.ws + (u64)(wave * S) * p.ws_stride;
+        ws = wbase;
     const u32 limit = p.retry ? *p.retry_count : p.n;
     for (;;) {
         u32 base = 0;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
                 job = p.retry_list[job];
             else if (p.order)
                 job = p.order[job];
-            decode_stream<1, false, S>(p, job, ws, shp, 0, &wlds[lane >> 6], tsp);
+            decode_stream<1, false, S>(p, job, ws, shp, 0, &wlds[lane >> 6], tsp, wbase);
         }
     }
 }

@@ -561,6 +561,12 @@ DEV u32 metablock(Ctx &c, u32 sub)
         rd_fail(r, CMP ? YS_MISMATCH : YS_CAPACITY);
         return 1;
     }
+    if (FLAT && got_of(c) + mlen > YS_LANE_MAX_OUT) {
+        /* a stream this long is one lane's work for too long: it goes to the retry pass, where a whole
+           wavefront decodes it with wide copies (k_decode<64>) */
+        rd_fail(r, YS_WORKSPACE);
+        return 1;
+    }
     if (!last && take(r, 1)) { /* ISUNCOMPRESSED :1050 */
         if (tail_nonzero(r)) {
             rd_fail(r, YS_INVALID);
@@ -801,7 +807,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
 /* yeast(): yeast.c:1353-1400 for one stream of the batch */
 template <int G, bool CMP, int FLAT>
 DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u32 sub, void *wl = nullptr,
-                       const struct TripShared *tsh = nullptr)
+                       const struct TripShared *tsh = nullptr, const u8 *ws_base = nullptr)
 {
     Ctx c;
 #ifdef YS_PROFILE
@@ -830,7 +836,7 @@ DEV void decode_stream(const ys_params &p, u32 job, u8 *ws, const Shared *sh, u3
     c.sh = sh;
     c.wl = wl;
     c.tsh = tsh;
-    c.ws_base = p.ws;
+    c.ws_base = ws_base ? ws_base : p.ws;
     c.L.num = c.I.num = c.D.num = 1;
     rd_seek(c.r, c.src, 0);
     if (s1 - s0 >= (1u << 29))

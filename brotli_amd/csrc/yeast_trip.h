@@ -10,20 +10,20 @@
  *
  *   1. the entry requested on the last trip arrives: consume the code and the extra bits that belong
  *      to it (insert/copy extra bits, distance extra bits) from a 64-bit funnel over the input words;
- *   2. decide what the stream decodes next and where that table is (literal context -> table through
- *      the wavefront's LDS map), and REQUEST THAT ENTRY AT ONCE;
- *   3. under that request's latency, do everything else: the distance value and the ring buffer
- *      (distance() yeast.c:761-789), the static dictionary reference (dict_word() yeast.c:908-949, a
- *      copy from the expanded dictionary), the copy set-up and its validity checks, the store of the
- *      piece loaded on the last trip and the load of the next one.
+ *   2. bytes: store the piece loaded on the last trip and this trip's literal; the distance value and
+ *      the ring buffer (distance() yeast.c:761-789), the static dictionary reference (dict_word()
+ *      yeast.c:908-949, a copy from the expanded dictionary), the copy set-up with its validity checks,
+ *      and the load of the copy's next piece;
+ *   3. decide what the stream decodes next and where that table is (literal context -> table through
+ *      the wavefront's LDS map) and request that entry and the input top-up; the loop back runs
+ *      under their latency.
  *
  * Bytes are moved by a per-stream copy engine in pieces of up to 16 bytes: one 16-byte load when the
  * piece is set up, one 16-byte store a trip later; the literal context after a copy comes from the
- * loaded registers.  Overlapping copies (byte-serial semantics, yeast.c:1285-1293) go in pieces no
+ * bytes loaded with it.  Overlapping copies (byte-serial semantics, yeast.c:1285-1293) go in pieces no
  * longer than their period, the period doubling with every whole period written.  A copy of up to 16
  * bytes (98 % of the copies of text) costs no trip of its own: the next command's symbol is requested
- * before the copy is set up (speculatively: when the copy turns out to need more pieces, or the
- * meta-block ends with it, the entry is dropped).
+ * on the trip that sets the copy up.
  *
  * The code is written without divergent branches: every step is computed for all lanes and selected,
  * memory operations are masked, and the rare cases (block switches, the last bytes of an output
@@ -594,6 +594,10 @@ template <int S>
 DEV void run_trip(Ctx &c, u32 &mlen, const FlatEnv &fe)
 {
     Rd &r = c.r;
+    if (got_of(c) + mlen >= 0xffffff00ull) { /* the loop counts output bytes in 32 bits: 4 GiB per stream and more are refused */
+        rd_fail(r, YS_NOMEM);
+        return;
+    }
     TripIn a;
     a.ws_base = c.ws_base; a.src = c.src; a.out = c.out; a.xdict = c.xdict;
     a.outp = c.outp;

@@ -37,20 +37,24 @@ def balanced_shards(weights: Sequence[int], nshards: int) -> List[Tuple[int, int
     return [(cuts[k], cuts[k + 1]) for k in range(nshards)]
 
 
-def all_gather_records(local, dist=None, group=None):
+def all_gather_records(local, dist=None, group=None, sizes=None):
     """All-gather per-stream 32-byte records.  `local` is a uint8 torch tensor
     of shape [n_local * 32] (CPU with gloo, GPU with nccl).  Returns a uint8
-    tensor holding the records of rank 0, rank 1, ... in order."""
+    tensor holding the records of rank 0, rank 1, ... in order.  `sizes` (bytes
+    per rank), when the caller knows the shards, saves the exchange of counts."""
     import torch
     if dist is None:
         import torch.distributed as dist
     world = dist.get_world_size(group)
     if world == 1:
         return local.clone()
-    count = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(count) for _ in range(world)]
-    dist.all_gather(counts, count, group=group)
-    sizes = [int(c.item()) for c in counts]
+    if sizes is None:
+        count = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+        counts = [torch.zeros_like(count) for _ in range(world)]
+        dist.all_gather(counts, count, group=group)
+        sizes = [int(c.item()) for c in counts]
+    elif len(sizes) != world or sizes[dist.get_rank(group)] != local.numel():
+        raise ValueError("all_gather_records: sizes do not describe this group's shards")
     cap = max(sizes)
     if all(s == cap for s in sizes):
         out = torch.empty(cap * world, dtype=torch.uint8, device=local.device)

@@ -113,16 +113,49 @@ def test_synthesised_streams_cfg4(lanes, monkeypatch):
 @pytest.mark.parametrize("lanes", KERNELS)
 def test_large_window_streams_cfg5(lanes, monkeypatch):
     # BASELINE config 5: window bits 24 with 16 MiB back-references and copies of megabytes (single
-    # streams: a latency case); the batch kernel takes the 1 MiB-window one only
+    # streams: a latency case).  The batch kernel (lanes 1) hands streams of more
+    # than 1 MiB of output to its retry pass, a wavefront per stream.
     monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
     meta, streams = H.packed_streams("cfg5_streams")
     for m, s in zip(meta["streams"], streams):
-        if lanes == 1 and m["got"] > (4 << 20):
-            continue
         (rc, out, got, used, chk), = ba.yeast_batch([s], ba.CHECK_CRC32C)
         assert (rc, got, used) == (m["rc"], m["got"], m["used"]), m["name"]
         assert "%08x" % chk == m["crc32c"], m["name"]
         assert "%016x" % ba.xxh64(out) == m["xxh64"], m["name"]
+
+
+def test_large_streams_inside_a_large_batch():
+    # 8,192 streams through the default dispatch (the batch kernel, one stream per lane), among them the 18 MB
+    # stream with 16 MiB distances, the 2 MB one, and files of several meta-blocks (lcet10: 427 KB, alice29)
+    meta, streams = H.packed_streams("cfg2_streams")
+    m5, s5 = H.packed_streams("cfg5_streams")
+    files = {}
+    for name in ("lcet10.txt", "alice29.txt", "plrabn12.txt", "zeros"):
+        files[name] = (open(os.path.join(H.GOLD, "testdata", name + ".compressed"), "rb").read(),
+                       open(os.path.join(H.GOLD, "testdata", name), "rb").read())
+    batch = list(streams) * 32
+    want = [None] * len(batch)  # None: a cfg2 stream, checked by its fixture
+    special = {}
+    for k, (m, s) in enumerate(zip(m5["streams"], s5)):
+        special[97 + 1000 * k] = (s, m)
+    for k, name in enumerate(files):
+        special[5 + 2047 * (k + 1)] = (files[name][0], files[name][1])
+    for i, (s, w) in special.items():
+        batch[i] = s
+        want[i] = w
+    assert len(batch) == 8192
+    res = ba.yeast_batch(batch, ba.CHECK_XXH64)
+    for i, r in enumerate(res):
+        w = want[i]
+        if w is None:
+            m = meta["streams"][i % len(streams)]
+            assert (r[0], r[2], r[3]) == (0, m["got"], m["len"]), i
+            assert "%016x" % r[4] == m["xxh64"], i
+        elif isinstance(w, dict):
+            assert (r[0], r[2], r[3]) == (w["rc"], w["got"], w["used"]), w["name"]
+            assert "%016x" % r[4] == w["xxh64"], w["name"]
+        else:
+            assert r[0] == 0 and r[1] == w and r[3] == len(batch[i]), i
 
 
 @pytest.mark.parametrize("lanes", [65, 64, 16, 8, 1, -1, -2, -3])
@@ -392,6 +425,12 @@ def test_br_container_reader_every_fixture():
         assert ba.sha256(msg) == hashlib.sha256(msg).digest()
     c, data = [x for x in cases if x[0]["name"] == "multi/text-12x64KiB"][0]
     assert ba.broad(data, write=False) == (0, b"", 12)
+    # a header inside another header's extra field, found by the index from the end with another kind of check in
+    # front of the same stream: the decode-ahead result must not be used for the real header (verifying only, too)
+    nested = [x for x in cases if x[0]["name"].startswith("crafted/header-inside-extra")]
+    assert len(nested) == 3
+    for c, data in nested:
+        assert ba.broad(data, write=False) == (c["rc"], b"", 2), c["name"]
 
 
 def test_br_writer_and_merger_byte_exact():

@@ -201,3 +201,65 @@ def test_compare_mode_against_the_reference_fixtures():
         assert (rc, got, used) == (c["rc"], c["got"], c["used"]), c
         n += 1
     assert n > 400
+
+
+def test_restatement_under_address_and_ub_sanitizers(tmp_path):
+    # the restatement itself, built with AddressSanitizer + UBSan as a program of its
+    # own (`make -C oracle asan`, oracle/asan_driver.c), over the fixtures and over damaged streams: same
+    # results as the fixtures say, and no report from either sanitizer
+    import random
+    import struct
+    import subprocess
+    odir = os.path.join(H.ROOT, "oracle")
+    r = subprocess.run(["make", "-C", odir, "asan"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode:
+        pytest.skip("no sanitizer runtime for this compiler: " + r.stdout.decode()[-200:])
+    cases, want = [], []
+
+    def add(kind, data, expected=None, res=None):
+        cases.append(struct.pack("<IQ", kind, len(data)) + data +
+                     (struct.pack("<Q", len(expected)) + expected if kind == 1 else b""))
+        want.append(res)
+    idx = H.load_json("testdata.json")
+    for name, comp, orig in H.testdata_pairs():
+        x = "%016x" % H.oracle().oracle_xxh64(orig, len(orig), 0)
+        add(0, comp, None, (0, idx[name]["got"], idx[name]["used"], x))
+        add(1, comp, orig, (0, len(orig), idx[name]["used"], None))
+    for name, v in H.load_json("crafted.json").items():
+        add(0, bytes.fromhex(v["hex"]), None, (v["rc"], v["got"], v["used"], None))
+    for fixture in ("cfg2_streams", "misc_streams", "cfg4_streams", "cfg5_streams"):
+        meta, streams = H.packed_streams(fixture)
+        for k, (m, s) in enumerate(zip(meta["streams"], streams)):
+            if fixture == "cfg2_streams" and k % 8:
+                continue
+            add(0, s, None, (m.get("rc", 0), m["got"], m.get("used", m["len"]), m["xxh64"]))
+    for c, comp, expected in cmp_cases():
+        add(1, comp, expected, (c["rc"], c["got"], c["used"], None))
+    for k, (c, data) in enumerate(H.br_cases()):
+        if c["name"].startswith(("damage/", "cut/")) and k % 4:
+            continue
+        add(2, data, None, None if c.get("reference_undefined") else (c["rc"], c["out_len"], None, c["out_xxh64"]))
+    rnd = random.Random(11)
+    meta, streams = H.packed_streams("cfg2_streams")
+    for t in range(400):  # damaged and truncated streams: only the sanitizers judge these
+        s = bytearray(streams[t % 7][:rnd.randrange(1, 6000)])
+        for _ in range(rnd.randrange(0, 4)):
+            s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+        add(0, bytes(s))
+    path = tmp_path / "cases.bin"
+    path.write_bytes(struct.pack("<I", len(cases)) + b"".join(cases))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([os.path.join(odir, "_asan", "oracle_asan"), str(path)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=900)
+    assert p.returncode == 0 and not p.stderr, p.stderr.decode()[-3000:]
+    lines = p.stdout.decode().split("\n")[:-1]
+    assert len(lines) == len(cases)
+    for k, (line, w) in enumerate(zip(lines, want)):
+        if w is None:
+            continue
+        rc, a, b, x = line.split()
+        assert int(rc) == w[0] and int(a) == w[1], (k, line, w)
+        if w[2] is not None:
+            assert int(b) == w[2], (k, line, w)
+        if w[3] is not None and w[0] == 0:
+            assert x == w[3], (k, line, w)

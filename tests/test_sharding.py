@@ -32,6 +32,10 @@ def _worker(rank, world, port, counts, q):
     n = counts[rank]
     local = torch.full((n * 32,), rank + 1, dtype=torch.uint8)
     out = all_gather_records(local, dist)
+    known = all_gather_records(local, dist, sizes=[c * 32 for c in counts])  # shard sizes known: no count exchange
+    assert torch.equal(out, known)
+    with pytest.raises(ValueError):
+        all_gather_records(local, dist, sizes=[c * 32 + 32 for c in counts])
     q.put((rank, out.numpy().tobytes()))
     dist.barrier()
     dist.destroy_process_group()

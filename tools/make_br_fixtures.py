@@ -210,6 +210,38 @@ for tk in (7, 0, 1, 2, 3, 4, 5, 6):
         tot += len(plain(s))
     add("stream/trailer-kind-%d" % tk, b"\xce\xb2\xcf\x81" + b"".join(segs) + trailer(tk, None, tot if tk % 2 else None, checks))
 
+# a header that sits inside another header's extra field: a later header's reverse offset points at it, so a
+# reader that indexes the file from the end sees it (with another kind of check) in front of the same stream,
+# while the walk from the front goes through the real header and fails only at the later header's offset
+def nested(kind_a, kind_in):
+    seg0 = segment(td("quickfox"), plain("quickfox"), 0, with_len=True)
+    A = 4 + len(seg0)
+    mask_a = kind_a | 8 | 0x10 | 0x40
+    head = bytearray([mask_a ^ par(mask_a)]) + var(A - 4)
+    if kind_a == 7:
+        head.append(0)
+    head.append(4 ^ par(4))
+    mask_in = kind_in | 8 | 0x10
+    inner_at = A + len(head) + 1  # behind the one-byte length of the extra field
+    inner = bytes([mask_in ^ par(mask_in)]) + var(inner_at - 4)
+    assert len(inner) < 0x80
+    head += var(len(inner)) + inner
+    pa = plain("xyzzy")
+    if kind_a == 7:
+        import hashlib
+        seg_a = bytes(head) + td("xyzzy") + var(len(pa)) + hashlib.sha256(pa).digest()
+    else:
+        seg_a = bytes(head) + td("xyzzy") + var(len(pa)) + chk(kind_a, pa)
+    B = A + len(seg_a)
+    seg_b = segment(td("x"), plain("x"), 0, with_len=True, off=B - inner_at)  # not B - A: the walk stops here
+    T = B + len(seg_b)
+    body = b"\xce\xb2\xcf\x81" + seg0 + seg_a + seg_b
+    return body + trailer(0, T - B, len(plain("quickfox")) + len(pa) + len(plain("x")), b"")
+for ka, ki in ((3, 4), (7, 3), (4, 2), (2, 7)):
+    if ki == 7:
+        continue  # an inner SHA-256 header needs its method byte: not this shape
+    add("crafted/header-inside-extra-%d-%d" % (ka, ki), nested(ka, ki))
+
 # damage: every byte of two small merged files under three masks, every truncation, and damage at
 # random places of larger ones (most of it lands in compressed data)
 rnd = random.Random(20260501)
