@@ -139,7 +139,7 @@ def test_large_streams_inside_a_large_batch():
     for k, (m, s) in enumerate(zip(m5["streams"], s5)):
         special[97 + 1000 * k] = (s, m)
     for k, name in enumerate(files):
-        special[5 + 2047 * (k + 1)] = (files[name][0], files[name][1])
+        special[5 + 2040 * (k + 1)] = (files[name][0], files[name][1])
     for i, (s, w) in special.items():
         batch[i] = s
         want[i] = w
