@@ -443,7 +443,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         stride = YS_WS_ARENA + 8192;
     if (flat && stride > (1u << 20))
         stride = 1u << 20; /* the batch kernel keeps table offsets >> 4 in 16 bits */
-    if (grow(d.ws, (size_t)groups * stride))
+    if (grow(d.ws, (size_t)groups * stride + 256))
         return -1;
     p.ws = (u8 *)d.ws.p;
     p.ws_stride = stride;

@@ -38,6 +38,10 @@ struct TripLds {
     u16 lt[64 * S]; /* literal table (byte offset >> 4) per context, current literal block type */
     u16 dt[4 * S];  /* distance table per distance context, current distance block type */
     u32 bt[6 * S];  /* block-switch tables (byte offsets): type code, count code of the three categories */
+    /* where the loop's loads land, by lane (not by stream slot): the table entry, the input top-up, the copy's piece */
+    u32 ent[64];
+    u32x4 top[64];
+    u32x4 piece[64];
 };
 
 /* LDS image shared by the wavefronts of a block */
@@ -116,6 +120,31 @@ struct TripOut {
     u32 r0, r1, r2, r3, mlen, rc, dry, pos;
 };
 
+/* Loads that land in the wavefront's LDS instead of registers (lane i's bytes at base + i * size), for the lanes
+   in `mask`; always issued, with no lane enabled if need be, so that the number of loads in flight behind a given one
+   is known.  The compiler keeps no count of them: the loop waits for them itself (s_waitcnt vmcnt below). */
+DEV void lds_load4(const u8 *sbase, u32 voff, u32 lds, u64 mask)
+{
+    u64 keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds), "s"(mask) : "memory");
+}
+DEV void lds_load16(const u8 *src, u32 lds, u64 mask)
+{
+    u64 keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds), "s"(mask) : "memory");
+}
+DEV void lds_load16_nt(const u8 *src, u32 lds, u64 mask) /* read once: not worth a place in L2 */
+{
+    u64 keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds), "s"(mask) : "memory");
+}
+
 template <int S>
 NOINL TripOut run_trip_fn(TripIn a)
 {
@@ -134,6 +163,10 @@ NOINL TripOut run_trip_fn(TripIn a)
     const u32 cap = a.cap;
     u32 mlen = a.mlen;
     u32 rc = 0, dry = 0;
+    /* the three landing places of this wavefront's loads */
+    const u32 lds_ent = uni((u32)(uintptr_t)&wl->ent[0]);
+    const u32 lds_top = uni((u32)(uintptr_t)&wl->top[0]);
+    const u32 lds_piece = uni((u32)(uintptr_t)&wl->piece[0]);
 
     /* ---- per-type tables of the current block types ---- */
     const u32 w_ltab = a.w_ltab;
@@ -177,9 +210,9 @@ NOINL TripOut run_trip_fn(TripIn a)
     }
     const bool any_switching = __any(switching);
 
-    /* ---- input: six words behind the bit offset bo (< 32 at the head of a trip); 64 bits from bo come out of
-       d0..d2 by two funnel shifts.  Topped up by one 8-byte load per trip while four words or fewer are held. */
-    u32 d0, d1, d2, d3, d4, d5, nq = 6, bo;
+    /* ---- input: eight words behind the bit offset bo (< 32 at the head of a trip); 64 bits from bo come out of
+       d0..d2 by two funnel shifts.  Topped up by one 16-byte load while four words or fewer are held. */
+    u32 d0, d1, d2, d3, d4, d5, d6, d7, nq = 8, bo;
     const u8 *ip;
     u32 endrel; /* bits from bit 0 of d0 to the end of the stream */
     {
@@ -189,38 +222,29 @@ NOINL TripOut run_trip_fn(TripIn a)
         ip = at - mis;
         bo = mis * 8 + (bitpos & 7);
         endrel = a.total - bitpos + bo;
-        u64 q0 = gld64u(ip), q1 = gld64u(ip + 8), q2 = gld64u(ip + 16);
-        d0 = (u32)q0; d1 = (u32)(q0 >> 32); d2 = (u32)q1; d3 = (u32)(q1 >> 32); d4 = (u32)q2; d5 = (u32)(q2 >> 32);
-        ip += 24;
+        u32x4 q0 = gld128u(ip), q1 = gld128u(ip + 16);
+        d0 = q0.x; d1 = q0.y; d2 = q0.z; d3 = q0.w; d4 = q1.x; d5 = q1.y; d6 = q1.z; d7 = q1.w;
+        ip += 32;
     }
-    u64 tq = 0; /* the top-up in flight (requested while nq <= 4, merged at the head of the next trip) */
 
     /* ---- output and copy engine ---- */
     u8 *op = a.outp;
     u32 p1 = a.p1 & 255, p2 = a.p2 & 255;
     u32 r0 = a.r0, r1 = a.r1, r2 = a.r2, r3 = a.r3;
-    u32 insert = 0, copy = 0, implicit = 0, dctx = 0;
+    u32 insert = 0, copy = 0, dctx = 0;
     u32 dsym = 0, dxv = 0;
     const u8 *csrc = a.outp; /* copy in progress: source of the next piece, bytes left, period limit */
     u32 crem = 0, cD = 0;
-    u32x4 pv = {0, 0, 0, 0}; /* the piece loaded on the last trip; it goes to op - pn */
-    u32 pn = 0;
+    u32 pn = 0; /* bytes of the piece requested on the last trip (it lands in wl->piece and goes to op - pn) */
 
-    /* ---- the lookup in flight ---- */
+    /* ---- the lookup in flight (its entry lands in wl->ent) ---- */
     u32 st = YT_CMD, cat = 0;
     u32 la = 0, lw = 0, lk = 0; /* table base (offset from wsb), index width; lk: root width of the code whose
                                    second half is being looked up, else 0 */
     u32 lo = 0, hi = 0;         /* 64 bits of input from bo */
-    u32 e = 0;
     u32 treq = 0;               /* a top-up is in flight */
     u32 after = YT_DIST;        /* what follows the literals of the command: YT_DIST, or YT_START = the copy */
-    u32 cx = 0, cxn = 0;        /* the last two bytes of the piece requested on the last trip (cxn of them) */
 #define YT_START 8u
-#ifdef YS_PROFILE
-#define TMARK(i) do { u64 now_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); pt[i] += now_ - plast; plast = now_; } while (0)
-#else
-#define TMARK(i) do { } while (0)
-#endif
 
     /* what a stream decodes next: w = category wanted (0..2).  A used-up block count turns it into a block
        switch first (yeast.c:1168-1180, 1192-1204, 1239-1251). */
@@ -250,34 +274,37 @@ NOINL TripOut run_trip_fn(TripIn a)
         d2 = adv ? d3 : d2;
         d3 = adv ? d4 : d3;
         d4 = adv ? d5 : d4;
+        d5 = adv ? d6 : d5;
+        d6 = adv ? d7 : d6;
         nq -= adv;
         u32 step = adv ? 32u : 0u;
         endrel -= step;
         bo -= step;
     };
-    /* request the entry of the lookup described by (la, lw) for the lanes in `on`, and the input top-up */
+    /* The three loads of a trip, always in this order and always all three (with no lane enabled if need be):
+       the entry of the lookup described by (la, lw) for the lanes in `on`, the input top-up -- and, by the caller
+       when the copy is set up, the copy's next piece.  So the entry has arrived when two loads or fewer are in
+       flight, whatever the stores of the trip (issued before it) are doing. */
     auto request = [&](bool on) {
         advance();
         if (__any(bo >= 32))
             advance();
         lo = __builtin_amdgcn_alignbit(d1, d0, bo);
         hi = __builtin_amdgcn_alignbit(d2, d1, bo);
-        if (on)
-            e = sld16(wsb, la + (__builtin_amdgcn_ubfe(lo, 0, lw) << 1));
-        treq = nq <= 4 && st != YT_END;
-        if (treq)
-            tq = gld64u(ip);
+        lds_load4(wsb, la + (__builtin_amdgcn_ubfe(lo, 0, lw) << 1), lds_ent, __ballot(on));
+        /* no more top-ups once the queue holds the rest of the stream: nothing is read far beyond its end */
+        treq = nq <= 4 && st != YT_END && endrel > nq * 32;
+        lds_load16(ip, lds_top, __ballot(treq != 0));
     };
 
     enter(true, YT_CMD, offI, left0, left1, left2);
     request(true);
-    asm volatile("" : "+v"(offI), "+v"(kmode), "+v"(d0), "+v"(d5));
+    lds_load16_nt(csrc, lds_piece, 0);
+    asm volatile("" : "+v"(offI), "+v"(kmode), "+v"(d0), "+v"(d7));
 
 #ifdef YS_PROFILE
     u32 ntrip = 0;
-    u64 pwait = 0, pbody = 0, plast;
-    u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(plast)::"memory");
+    u64 pwait = 0, pwait2 = 0;
     const u64 t_loop = __builtin_amdgcn_s_memrealtime();
 #endif
     /* No stream needs more trips than this (a trip that neither writes a byte nor reads a bit is a block switch
@@ -293,34 +320,25 @@ NOINL TripOut run_trip_fn(TripIn a)
             budget = v > budget ? v : budget;
         }
     }
-    while (__any(st != YT_END)) {
+    while (__any(st != YT_END || crem != 0)) {
         if (--budget == 0) {
-            rc = st != YT_END && !rc ? (u32)YS_WORKSPACE : rc;
+            rc = (st != YT_END || crem != 0) && !rc ? (u32)YS_WORKSPACE : rc;
             break;
         }
+        /* ================= 1. the entry arrives: consume it ================= */
 #ifdef YS_PROFILE
         ntrip++;
-        {
-            u64 ta, tb;
-            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta)::"memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb)::"memory");
-            pwait += tb - ta;
-            pt[7] += ta - plast;
-            plast = tb;
-        }
+        u64 ta_, tb_;
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta_)::"memory");
 #endif
-        /* ================= 1. the entry arrives: consume it ================= */
-        {
-            const bool got2 = treq != 0;
-            u32 t0 = (u32)tq, t1 = (u32)(tq >> 32);
-            d3 = got2 && nq == 3 ? t0 : d3;
-            d4 = got2 ? (nq == 3 ? t1 : t0) : d4;
-            d5 = got2 && nq == 4 ? t1 : d5;
-            ip += got2 ? 8 : 0;
-            nq += got2 ? 2 : 0;
-        }
-        const bool active = st <= YT_BC;
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
+        pwait += tb_ - ta_;
+#endif
+        const u32 e = wl->ent[slot] & 0xffff;
+        const bool hold = crem != 0; /* a copy of several pieces is going on: the entry waits */
+        const bool active = st <= YT_BC && !hold;
         u32 l = e & 15, sym = e >> 4;
         const bool is_link = active && lk == 0 && l > lw;
         u32 nb = is_link ? lw : l - lk;
@@ -358,17 +376,6 @@ NOINL TripOut run_trip_fn(TripIn a)
             bo += dC || dD ? ext : 0;
         }
         insert = dC ? ins_new : insert - dL;
-        /* literal context: the bytes of a literal, or the last two bytes of the piece requested on the last trip */
-        {
-            u32 c1 = cxn >= 2 ? (cx >> 8) & 255 : cx & 255, c2 = cxn >= 2 ? cx & 255 : p1;
-            u32 n1 = dL ? sym : c1, n2 = dL ? p1 : c2;
-            const bool upd = dL || cxn != 0;
-            p2 = upd ? n2 : p2;
-            p1 = upd ? n1 : p1;
-            cxn = 0;
-        }
-        u8 *const lit_at = op;
-        op += dL;
         left0 -= dC && switching;
         left1 -= dL && switching;
         left2 -= dD && switching;
@@ -398,7 +405,7 @@ NOINL TripOut run_trip_fn(TripIn a)
             left0 = okN && cat == YT_CMD ? cnt : left0;
             left1 = okN && cat == YT_LIT ? cnt : left1;
             left2 = okN && cat == YT_DIST ? cnt : left2;
-            if (okN) { /* the new type's tables */
+            if (okN) { /* the new type's tables (ordinary loads: the compiler waits for them, and for all else) */
                 u32 ty = (type3 >> sh) & 255;
                 if (cat == YT_CMD)
                     offI = wso + sld32(wsb, wso + YS_WS_ITAB + ty * 4);
@@ -419,37 +426,86 @@ NOINL TripOut run_trip_fn(TripIn a)
         asm volatile("" : "+v"(offI), "+v"(kmode));
         eof = eof || (active && bo > endrel);
 
-        TMARK(0);
-        /* ================= 2. bytes: the copy that begins or goes on, its piece requested first of all ================= */
-        /* the copy in progress ends with the piece set up on this trip */
-        u32 m = crem < 16 ? crem : 16;
-        m = m < cD ? m : cD;
-        const bool fin = st == YT_COPY && m == crem;
+        /* ================= 2. the other two loads of the last trip: input words, the copy's piece ================= */
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta_)::"memory");
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
+        pwait2 += tb_ - ta_;
+#endif
+        {
+            const bool got4 = treq != 0;
+            const u32x4 tv = wl->top[slot];
+            const bool at3 = nq == 3; /* else 4 */
+            d3 = got4 && at3 ? tv.x : d3;
+            d4 = got4 ? (at3 ? tv.y : tv.x) : d4;
+            d5 = got4 ? (at3 ? tv.z : tv.y) : d5;
+            d6 = got4 ? (at3 ? tv.w : tv.z) : d6;
+            d7 = got4 && !at3 ? tv.w : d7;
+            ip += got4 ? 16 : 0;
+            nq += got4 ? 4 : 0;
+        }
+        /* the piece goes out (a whole unit; the excess is overwritten by what follows), then this trip's literal;
+           the literal context: the last two bytes of the piece, or the literal */
+        if (pn) {
+            const LAS u8 *pb = (const LAS u8 *)&wl->piece[slot];
+            u32 b1 = pb[pn - 1], b2 = pb[pn >= 2 ? pn - 2 : 0];
+            gst128u(op - pn, wl->piece[slot]);
+            p2 = pn >= 2 ? b2 : p1;
+            p1 = b1;
+        }
+        pn = 0;
+        if (dL)
+            gst8(op, sym);
+        p2 = dL ? p1 : p2;
+        p1 = dL ? sym : p1;
+        op += dL;
+
+        /* ================= 3. what comes next, and the request for it ================= */
         const bool lits = insert != 0;
         const bool cl = dC || dL;
-        const bool ends = (dL && !lits && mlen == 0) || (fin && mlen == 0) || eof; /* :1227, :1295 */
-        const bool to_after = cl && !lits && !ends;
-        const bool start = !rc && ((to_after && after == YT_START) || (dD && !eof)); /* a copy begins on this trip */
-        bool single = false; /* the copy that begins is one piece long and the meta-block goes on */
-        TMARK(1);
-        /* the piece loaded on the last trip (a whole unit; the excess is overwritten by what follows) and this
-           trip's literal go out before any byte is fetched: the next piece may begin with them */
-        if (pn)
-            gst128u(op - dL - pn, pv);
-        pn = 0;
-        TMARK(2);
-        if (dL)
-            gst8(lit_at, sym);
-        TMARK(3);
-        const u32 got = (u32)(uintptr_t)op - out_lo;
         { /* the insert length against what is left of the meta-block; end of input */
             const bool over = dC && !eof && insert > mlen; /* :1189 */
             mlen -= dC && !eof && !over ? insert : 0;
             dry = active && eof && !rc ? 1 : dry;
             rc = (active && eof) && !rc ? (u32)YS_EOF : rc;
             rc = over && !rc ? (u32)YS_INVALID : rc;
-            st = over ? YT_END : st;
         }
+        const bool ends = (dL && !lits && mlen == 0) || eof; /* :1227 */
+        const bool to_after = cl && !lits && !ends;
+        const bool start = !rc && ((to_after && after == YT_START) || (dD && !eof)); /* a copy begins on this trip */
+        const bool wantL = (cl && lits) || (redo && cat == YT_LIT);
+        const bool wantD = (to_after && after == YT_DIST) || (redo && cat == YT_DIST);
+        /* the next command's symbol is requested on the trip that sets the copy up, before the copy is known to be
+           valid and to leave something of the meta-block: if not, the entry is never looked at */
+        const bool wantC = start || (redo && cat == YT_CMD);
+        /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
+           distance context -> table (yeast.c:1253-1257 through dt) */
+        u32 offL = offL0, offD = offD0;
+        {
+            u32 f1 = ((const LAS u8 *)ts->kctx)[(kmode + p1) * 2];
+            u32 f2 = ((const LAS u8 *)ts->kctx)[(kmode + p2) * 2 + 1];
+            u32 cid = f1 | f2;
+            u32 mi = wantD ? 64 * S + dctx * S : cid * S; /* dt lies behind lt */
+            u32 o = (u32)((const LAS u16 *)wl->lt)[mi + slot] << 4;
+            offL = ctx ? wso + o : offL;
+            offD = dmap ? wso + o : offD;
+        }
+        const bool want = (wantL || wantD || wantC) && !rc && !eof;
+        {
+            u32 w = wantL ? YT_LIT : wantD ? YT_DIST : YT_CMD;
+            u32 off_w = wantL ? offL : wantD ? offD : offI;
+            enter(want, w, off_w, left0, left1, left2);
+        }
+        st = rc || ends ? YT_END : st;
+        request(st <= YT_BC && (want || is_link || (active && st >= YT_BT)));
+
+        /* ================= 4. under those loads: the copy that begins or goes on, its next piece ================= */
+        const u32 got = (u32)(uintptr_t)op - out_lo;
+        u32 m = crem < 16 ? crem : 16;
+        m = m < cD ? m : cD;
         {
             /* distance(): yeast.c:761-789 (every lane computes it; the lanes in `start` use it).  Ring buffer
                entry and offset per symbol below 16 from packed constants: -1 +1 -2 +2 -3 +3 on the last and the
@@ -501,13 +557,9 @@ NOINL TripOut run_trip_fn(TripIn a)
             u32 m2 = crem < 16 ? crem : 16;
             m2 = m2 < cD ? m2 : cD;
             m = start ? m2 : m;
-            /* a copy of one piece costs no trip of its own: the next command's symbol is requested below */
-            u32 nst = m == crem ? (mlen == 0 ? YT_END : st) : YT_COPY;
-            nst = bad ? YT_END : nst;
-            st = start ? nst : st;
-            single = go && m == crem && mlen != 0;
+            /* the meta-block ends with this copy (:1295), or the copy is no good: the entry requested above is dropped */
+            st = bad || (go && mlen == 0) ? YT_END : st;
         }
-        TMARK(4);
         /* the next piece of the copy in progress: requested now, stored on the next trip */
         {
             const bool piece = crem != 0;
@@ -527,59 +579,29 @@ NOINL TripOut run_trip_fn(TripIn a)
             }
             m = piece ? m : 0;
             const bool ld = piece && !tail;
-            if (ld) {
-                pv = gld128u_nt(csrc); /* read once, far back in the output: not worth a place in L2 */
-                cx = gld16u(csrc + (m >= 2 ? m - 2 : 0));
-            }
+            lds_load16_nt(csrc, lds_piece, __ballot(ld));
             pn = ld ? m : 0;
-            cxn = ld ? (m >= 2 ? 2u : 1u) : 0;
             op += m;
             crem -= m;
             const bool whole = m == cD; /* a whole period is written: twice as far back is the same data */
             cD = whole ? cD * 2 : cD;
             csrc += whole ? 0 : m;
         }
-        TMARK(5);
-        /* ================= 3. what comes next, and the request for it ================= */
-        const bool wantL = (cl && lits) || (redo && cat == YT_LIT);
-        const bool wantD = (to_after && after == YT_DIST) || (redo && cat == YT_DIST);
-        const bool wantC = single || (fin && mlen != 0) || (redo && cat == YT_CMD);
-        /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
-           distance context -> table (yeast.c:1253-1257 through dt) */
-        u32 offL = offL0, offD = offD0;
-        {
-            u32 f1 = ((const LAS u8 *)ts->kctx)[(kmode + p1) * 2];
-            u32 f2 = ((const LAS u8 *)ts->kctx)[(kmode + p2) * 2 + 1];
-            u32 cid = f1 | f2;
-            u32 mi = wantD ? 64 * S + dctx * S : cid * S; /* dt lies behind lt */
-            u32 o = (u32)((const LAS u16 *)wl->lt)[mi + slot] << 4;
-            offL = ctx ? wso + o : offL;
-            offD = dmap ? wso + o : offD;
-        }
-        {
-            const bool want = (wantL || wantD || wantC) && !rc && !eof;
-            u32 w = wantL ? YT_LIT : wantD ? YT_DIST : YT_CMD;
-            u32 off_w = wantL ? offL : wantD ? offD : offI;
-            enter(want, w, off_w, left0, left1, left2);
-        }
-        st = rc || ends ? YT_END : st;
-        TMARK(6);
-        request(st <= YT_BC);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef YS_PROFILE
     if ((threadIdx.x & 63) == 0 && cap >= 128) { /* the profile build's output bytes are not meant to be looked at */
         u64 *prof = (u64 *)(a.out + cap - 128);
         prof[12] = ntrip;
         prof[2] = pwait;
-        for (int i = 0; i < 8; i++)
-            prof[3 + i] = pt[i];
+        prof[3] = pwait2;
         prof[13] = t_loop - a.t_start;
         prof[14] = __builtin_amdgcn_s_memrealtime() - t_loop;
     }
 #endif
     /* meta-block end (or failure): the piece set up last was valid */
     if (pn)
-        gst128u(op - pn, pv);
+        gst128u(op - pn, wl->piece[slot]);
     TripOut o;
     o.outp = op;
     o.r0 = r0; o.r1 = r1; o.r2 = r2; o.r3 = r3;
