@@ -285,12 +285,14 @@ NOINL TripOut run_trip_fn(TripIn a)
        the entry of the lookup described by (la, lw) for the lanes in `on`, the input top-up -- and, by the caller
        when the copy is set up, the copy's next piece.  So the entry has arrived when two loads or fewer are in
        flight, whatever the stores of the trip (issued before it) are doing. */
-    auto request = [&](bool on) {
+    auto peek = [&]() {
         advance();
         if (__any(bo >= 32))
             advance();
         lo = __builtin_amdgcn_alignbit(d1, d0, bo);
         hi = __builtin_amdgcn_alignbit(d2, d1, bo);
+    };
+    auto request = [&](bool on) {
         lds_load4(wsb, la + (__builtin_amdgcn_ubfe(lo, 0, lw) << 1), lds_ent, __ballot(on));
         /* no more top-ups once the queue holds the rest of the stream: nothing is read far beyond its end */
         treq = nq <= 4 && st != YT_END && endrel > nq * 32;
@@ -298,13 +300,14 @@ NOINL TripOut run_trip_fn(TripIn a)
     };
 
     enter(true, YT_CMD, offI, left0, left1, left2);
+    peek();
     request(true);
     lds_load16_nt(csrc, lds_piece, 0);
     asm volatile("" : "+v"(offI), "+v"(kmode), "+v"(d0), "+v"(d7));
 
 #ifdef YS_PROFILE
     u32 ntrip = 0;
-    u64 pwait = 0, pwait2 = 0;
+    u64 pwait = 0, pwait2 = 0, pwait3 = 0;
     const u64 t_loop = __builtin_amdgcn_s_memrealtime();
 #endif
     /* No stream needs more trips than this (a trip that neither writes a byte nor reads a bit is a block switch
@@ -430,7 +433,7 @@ NOINL TripOut run_trip_fn(TripIn a)
 #ifdef YS_PROFILE
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta_)::"memory");
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #ifdef YS_PROFILE
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
         pwait2 += tb_ - ta_;
@@ -447,23 +450,7 @@ NOINL TripOut run_trip_fn(TripIn a)
             ip += got4 ? 16 : 0;
             nq += got4 ? 4 : 0;
         }
-        /* the piece goes out (a whole unit; the excess is overwritten by what follows), then this trip's literal;
-           the literal context: the last two bytes of the piece, or the literal */
-        if (pn) {
-            const LAS u8 *pb = (const LAS u8 *)&wl->piece[slot];
-            u32 b1 = pb[pn - 1], b2 = pb[pn >= 2 ? pn - 2 : 0];
-            gst128u(op - pn, wl->piece[slot]);
-            p2 = pn >= 2 ? b2 : p1;
-            p1 = b1;
-        }
-        pn = 0;
-        if (dL)
-            gst8(op, sym);
-        p2 = dL ? p1 : p2;
-        p1 = dL ? sym : p1;
-        op += dL;
-
-        /* ================= 3. what comes next, and the request for it ================= */
+        peek();
         const bool lits = insert != 0;
         const bool cl = dC || dL;
         { /* the insert length against what is left of the meta-block; end of input */
@@ -481,6 +468,34 @@ NOINL TripOut run_trip_fn(TripIn a)
         /* the next command's symbol is requested on the trip that sets the copy up, before the copy is known to be
            valid and to leave something of the meta-block: if not, the entry is never looked at */
         const bool wantC = start || (redo && cat == YT_CMD);
+        const bool want = (wantL || wantD || wantC) && !rc && !eof;
+
+        /* the piece requested on the last trip (the youngest load: waited for as late as can be) goes out -- a whole
+           unit; the excess is overwritten by what follows -- then this trip's literal; the literal context: the last
+           two bytes of the piece, or the literal */
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta_)::"memory");
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
+        pwait3 += tb_ - ta_;
+#endif
+        if (pn) {
+            const LAS u8 *pb = (const LAS u8 *)&wl->piece[slot];
+            u32 b1 = pb[pn - 1], b2 = pb[pn >= 2 ? pn - 2 : 0];
+            gst128u(op - pn, wl->piece[slot]);
+            p2 = pn >= 2 ? b2 : p1;
+            p1 = b1;
+        }
+        pn = 0;
+        if (dL)
+            gst8(op, sym);
+        p2 = dL ? p1 : p2;
+        p1 = dL ? sym : p1;
+        op += dL;
+
+        /* ================= 3. what comes next, and the request for it ================= */
         /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
            distance context -> table (yeast.c:1253-1257 through dt) */
         u32 offL = offL0, offD = offD0;
@@ -493,7 +508,6 @@ NOINL TripOut run_trip_fn(TripIn a)
             offL = ctx ? wso + o : offL;
             offD = dmap ? wso + o : offD;
         }
-        const bool want = (wantL || wantD || wantC) && !rc && !eof;
         {
             u32 w = wantL ? YT_LIT : wantD ? YT_DIST : YT_CMD;
             u32 off_w = wantL ? offL : wantD ? offD : offI;
@@ -595,6 +609,7 @@ NOINL TripOut run_trip_fn(TripIn a)
         prof[12] = ntrip;
         prof[2] = pwait;
         prof[3] = pwait2;
+        prof[4] = pwait3;
         prof[13] = t_loop - a.t_start;
         prof[14] = __builtin_amdgcn_s_memrealtime() - t_loop;
     }

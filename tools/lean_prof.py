@@ -30,6 +30,6 @@ m = A.mean(0)
 print("trips per wavefront: mean %.0f max %.0f" % (m[12], A[:, 12].max()))
 print("header and tables %.2f ms, loop %.2f ms per wavefront (mean); slowest loop %.2f ms" % (m[13] / 1e5, m[14] / 1e5, A[:, 14].max() / 1e5))
 print("time per trip: %.0f ns" % (10 * m[14] / m[12]))
-print("cycles per trip: waiting at the head %.0f" % (m[2] / m[12]))
-for k, name in enumerate(["1 consume, block switch", "flags", "store of the last piece", "store of the literal", "mlen, distance, dictionary, copy set-up", "piece request", "3 next: states, context, enter", "request, loop back, wait"]):
-    print("  %-44s %6.0f" % (name, m[3 + k] / m[12]))
+print("cycles per trip waiting: for the entry (head) %.0f, for the input words %.0f, for the piece %.0f" % (m[2] / m[12], m[3] / m[12], m[4] / m[12]))
+slow = A[A[:, 14].argmax()]
+print("slowest wavefront: %.0f trips, %.0f ns per trip, waits %.0f + %.0f + %.0f cycles per trip" % (slow[12], 10 * slow[14] / slow[12], slow[2] / slow[12], slow[3] / slow[12], slow[4] / slow[12]))
