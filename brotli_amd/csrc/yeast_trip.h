@@ -120,29 +120,22 @@ struct TripOut {
     u32 r0, r1, r2, r3, mlen, rc, dry, pos;
 };
 
-/* Loads that land in the wavefront's LDS instead of registers (lane i's bytes at base + i * size), for the lanes
-   in `mask`; always issued, with no lane enabled if need be, so that the number of loads in flight behind a given one
-   is known.  The compiler keeps no count of them: the loop waits for them itself (s_waitcnt vmcnt below). */
-DEV void lds_load4(const u8 *sbase, u32 voff, u32 lds, u64 mask)
+/* Loads that land in the wavefront's LDS instead of registers (lane i's bytes at base + i * size).  The compiler
+   keeps no count of them: the loop waits for them itself (s_waitcnt vmcnt below), and for that count to be known
+   they are issued on every trip by every lane -- a lane with nothing to load reads the first bytes of the workspace
+   (one line for all such lanes) and ignores what lands.  (Switching lanes off in exec instead costs ~50 cycles per
+   load, tools/ubench/glds_issue.hip.) */
+DEV void lds_load4(const u8 *sbase, u32 voff, u32 lds)
 {
-    u64 keep;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds), "s"(mask) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
-DEV void lds_load16(const u8 *src, u32 lds, u64 mask)
+DEV void lds_load16(const u8 *src, u32 lds)
 {
-    u64 keep;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds), "s"(mask) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds) : "memory");
 }
-DEV void lds_load16_nt(const u8 *src, u32 lds, u64 mask) /* read once: not worth a place in L2 */
+DEV void lds_load16_nt(const u8 *src, u32 lds) /* read once: not worth a place in L2 */
 {
-    u64 keep;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b64 exec, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds), "s"(mask) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(src), "s"(lds) : "memory");
 }
 
 template <int S>
@@ -243,8 +236,15 @@ NOINL TripOut run_trip_fn(TripIn a)
                                    second half is being looked up, else 0 */
     u32 lo = 0, hi = 0;         /* 64 bits of input from bo */
     u32 treq = 0;               /* a top-up is in flight */
+    u32 e = 0;                  /* the entry last asked for */
+    bool asked = false;         /* an entry was asked for on the last trip */
     u32 after = YT_DIST;        /* what follows the literals of the command: YT_DIST, or YT_START = the copy */
 #define YT_START 8u
+#ifdef YS_PROFILE
+#define TMARK(i) do { u64 now_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); pt[i] += now_ - plast; plast = now_; } while (0)
+#else
+#define TMARK(i) do { } while (0)
+#endif
 
     /* what a stream decodes next: w = category wanted (0..2).  A used-up block count turns it into a block
        switch first (yeast.c:1168-1180, 1192-1204, 1239-1251). */
@@ -293,21 +293,24 @@ NOINL TripOut run_trip_fn(TripIn a)
         hi = __builtin_amdgcn_alignbit(d2, d1, bo);
     };
     auto request = [&](bool on) {
-        lds_load4(wsb, la + (__builtin_amdgcn_ubfe(lo, 0, lw) << 1), lds_ent, __ballot(on));
+        lds_load4(wsb, on ? la + (__builtin_amdgcn_ubfe(lo, 0, lw) << 1) : 0u, lds_ent);
+        asked = on;
         /* no more top-ups once the queue holds the rest of the stream: nothing is read far beyond its end */
         treq = nq <= 4 && st != YT_END && endrel > nq * 32;
-        lds_load16(ip, lds_top, __ballot(treq != 0));
+        lds_load16(treq ? ip : wsb, lds_top);
     };
 
     enter(true, YT_CMD, offI, left0, left1, left2);
     peek();
     request(true);
-    lds_load16_nt(csrc, lds_piece, 0);
+    lds_load16_nt(wsb, lds_piece);
     asm volatile("" : "+v"(offI), "+v"(kmode), "+v"(d0), "+v"(d7));
 
 #ifdef YS_PROFILE
     u32 ntrip = 0;
-    u64 pwait = 0, pwait2 = 0, pwait3 = 0;
+    u64 pwait = 0, pwait2 = 0, pwait3 = 0, plast;
+    u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(plast)::"memory");
     const u64 t_loop = __builtin_amdgcn_s_memrealtime();
 #endif
     /* No stream needs more trips than this (a trip that neither writes a byte nor reads a bit is a block switch
@@ -339,7 +342,8 @@ NOINL TripOut run_trip_fn(TripIn a)
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
         pwait += tb_ - ta_;
 #endif
-        const u32 e = wl->ent[slot] & 0xffff;
+        e = asked ? wl->ent[slot] & 0xffff : e; /* a stream in the middle of a copy keeps the entry it holds */
+        TMARK(0);
         const bool hold = crem != 0; /* a copy of several pieces is going on: the entry waits */
         const bool active = st <= YT_BC && !hold;
         u32 l = e & 15, sym = e >> 4;
@@ -428,6 +432,7 @@ NOINL TripOut run_trip_fn(TripIn a)
         }
         asm volatile("" : "+v"(offI), "+v"(kmode));
         eof = eof || (active && bo > endrel);
+        TMARK(1);
 
         /* ================= 2. the other two loads of the last trip: input words, the copy's piece ================= */
 #ifdef YS_PROFILE
@@ -469,6 +474,7 @@ NOINL TripOut run_trip_fn(TripIn a)
            valid and to leave something of the meta-block: if not, the entry is never looked at */
         const bool wantC = start || (redo && cat == YT_CMD);
         const bool want = (wantL || wantD || wantC) && !rc && !eof;
+        TMARK(2);
 
         /* the piece requested on the last trip (the youngest load: waited for as late as can be) goes out -- a whole
            unit; the excess is overwritten by what follows -- then this trip's literal; the literal context: the last
@@ -494,6 +500,7 @@ NOINL TripOut run_trip_fn(TripIn a)
         p2 = dL ? p1 : p2;
         p1 = dL ? sym : p1;
         op += dL;
+        TMARK(3);
 
         /* ================= 3. what comes next, and the request for it ================= */
         /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
@@ -514,8 +521,10 @@ NOINL TripOut run_trip_fn(TripIn a)
             enter(want, w, off_w, left0, left1, left2);
         }
         st = rc || ends ? YT_END : st;
+        TMARK(4);
         request(st <= YT_BC && (want || is_link || (active && st >= YT_BT)));
 
+        TMARK(5);
         /* ================= 4. under those loads: the copy that begins or goes on, its next piece ================= */
         const u32 got = (u32)(uintptr_t)op - out_lo;
         u32 m = crem < 16 ? crem : 16;
@@ -574,6 +583,7 @@ NOINL TripOut run_trip_fn(TripIn a)
             /* the meta-block ends with this copy (:1295), or the copy is no good: the entry requested above is dropped */
             st = bad || (go && mlen == 0) ? YT_END : st;
         }
+        TMARK(6);
         /* the next piece of the copy in progress: requested now, stored on the next trip */
         {
             const bool piece = crem != 0;
@@ -593,7 +603,7 @@ NOINL TripOut run_trip_fn(TripIn a)
             }
             m = piece ? m : 0;
             const bool ld = piece && !tail;
-            lds_load16_nt(csrc, lds_piece, __ballot(ld));
+            lds_load16_nt(ld ? csrc : wsb, lds_piece);
             pn = ld ? m : 0;
             op += m;
             crem -= m;
@@ -601,6 +611,7 @@ NOINL TripOut run_trip_fn(TripIn a)
             cD = whole ? cD * 2 : cD;
             csrc += whole ? 0 : m;
         }
+        TMARK(7);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef YS_PROFILE
@@ -610,6 +621,9 @@ NOINL TripOut run_trip_fn(TripIn a)
         prof[2] = pwait;
         prof[3] = pwait2;
         prof[4] = pwait3;
+        for (int i = 0; i < 7; i++)
+            prof[5 + i] = pt[i];
+        prof[15] = pt[7];
         prof[13] = t_loop - a.t_start;
         prof[14] = __builtin_amdgcn_s_memrealtime() - t_loop;
     }

@@ -23,7 +23,7 @@ offs = np.asarray(b.host_dst_off[:n + 1], dtype=np.int64)
 rows = []
 for i in range(0, n, S):
     e = int(offs[i + 1])
-    rows.append(host[e - 128:e - 128 + 120].view(np.uint64).astype(np.float64))
+    rows.append(host[e - 128:e].view(np.uint64).astype(np.float64))
 A = np.stack(rows)
 m = A.mean(0)
 # prof[12] = trips of the wavefront, [13] = header and tables, [14] = the loop (both in 10 ns units)
@@ -33,3 +33,9 @@ print("time per trip: %.0f ns" % (10 * m[14] / m[12]))
 print("cycles per trip waiting: for the entry (head) %.0f, for the input words %.0f, for the piece %.0f" % (m[2] / m[12], m[3] / m[12], m[4] / m[12]))
 slow = A[A[:, 14].argmax()]
 print("slowest wavefront: %.0f trips, %.0f ns per trip, waits %.0f + %.0f + %.0f cycles per trip" % (slow[12], 10 * slow[14] / slow[12], slow[2] / slow[12], slow[3] / slow[12], slow[4] / slow[12]))
+names = ["loop back, wait for the entry, entry read", "1 consume, block switch", "wait for the input words, merge, peek, flags",
+         "wait for the piece, stores, context bytes", "3 context -> table, enter", "request (entry, top-up)",
+         "4 distance, dictionary, copy set-up", "piece request"]
+for k, name in enumerate(names):
+    v = m[5 + k] if k < 7 else m[15]
+    print("  %-48s %6.0f" % (name, v / m[12]))
