@@ -17,262 +17,73 @@ in this image: it needs BSD digittoint()).
   p id s ...       symbols coded with code id
   ;  ends a command    #  starts a comment
 
+The command language is the reference's; the construction of the codes is this repo's own (tools/brosynth.py:
+heap Huffman with frequency flattening for the length limit, canonical assignment by (length, symbol), its own
+planner for the run-length symbols 16 and 17), not the reference's huff.c / flatten.c / complex().
+
 Pinning: tests/test_oracle_golden.py runs every .gen file of the reference through this program and
 compares with the bytes the reference's own tests produce from them (SURVEY section 4's table, which is
 tests/golden/crafted.json).  No .gen file of the reference uses `c`, so the bytes written for a complex
 code are unpinned; the test checks instead that the decoder restatement reads back the code that was asked for.
 Usage: tools/brogen.py < x.gen > x.compressed, or brogen(text) -> bytes.
 """
+import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from brosynth import BitWriter, canonical, write_lengths  # this repo's own code construction and descriptor writer
 
-class Bits:
-    """LSB-first bit writer (bout(): brogen.cc:221-255)."""
-
-    def __init__(self):
-        self.out = bytearray()
-        self.acc = 0
-        self.n = 0
-
-    def put(self, n, val):
-        self.acc |= (val & ((1 << n) - 1)) << self.n
-        self.n += n
-        while self.n >= 8:
-            self.out.append(self.acc & 255)
-            self.acc >>= 8
-            self.n -= 8
-
-    def flush(self, fill=0):
-        if self.n:
-            self.acc |= fill << self.n
-            self.out.append(self.acc & 255)
-            self.acc = 0
-            self.n = 0
+# the variable-length code of the code length code lengths 0..5 (RFC 7932 section 3.5), as (bits, value as the stream holds it)
+LEN_BITS = [(2, 0), (4, 7), (3, 3), (2, 2), (2, 1), (4, 15)]
 
 
-def canonical(count, symbols):
-    """{symbol: (bits, code reversed for the stream)} from counts per length and the symbols in canonical
-    order (encode(): brogen.cc:274-291)."""
-    enc = {}
-    count = list(count)
-    length, code, k = 0, 0, 0
-    while True:
-        while count[length] == 0:
-            length += 1
-        enc[symbols[k]] = (length, code)
-        k += 1
-        count[length] -= 1
-        bit = 1 << length  # add one to the code from its far end
-        while True:
-            bit >>= 1
-            if not bit:
-                break
-            code ^= bit
-            if code & bit:
-                break
-        if code == 0:
-            return enc
+class Out(BitWriter):
+    """The stream under construction: brosynth's bit writer behind the argument order of this file's commands."""
+
+    def bits(self, n, val):
+        self.put(val & ((1 << n) - 1), n)
+
+    def word(self, cw):
+        """a code word (code, length), most significant bit first"""
+        self.code(*cw)
+
+    def to_boundary(self, fill=0):
+        pad = -self.n & 7
+        self.put(fill & ((1 << pad) - 1), pad)
+
+    def raw(self, data):
+        self.to_boundary()
+        for v in data:
+            self.put(v & 255, 8)
 
 
-def huffman_lengths(freq):
-    """Code lengths for frequencies sorted ascending (huffman(): huff.c:14-70, Moffat and Katajainen's
-    in-place method); the lengths come out longest first."""
-    n = len(freq)
-    if n == 0:
-        return []
-    if n == 1:
-        return [0]
-    a = list(freq)
-    a[0] += a[1]
-    root, leaf = 0, 2
-    for nxt in range(1, n - 1):
-        if leaf >= n or a[root] < a[leaf]:
-            a[nxt] = a[root]
-            a[root] = nxt
-            root += 1
-        else:
-            a[nxt] = a[leaf]
-            leaf += 1
-        if leaf >= n or (root < nxt and a[root] < a[leaf]):
-            a[nxt] += a[root]
-            a[root] = nxt
-            root += 1
-        else:
-            a[nxt] += a[leaf]
-            leaf += 1
-    a[n - 2] = 0
-    for nxt in range(n - 3, -1, -1):
-        a[nxt] = a[a[nxt]] + 1
-    avail, used, depth = 1, 0, 0
-    root = nxt = n - 1
-    while avail:
-        while root and a[root - 1] == depth:
-            used += 1
-            root -= 1
-        while avail > used:
-            a[nxt] = depth
-            nxt -= 1
-            avail -= 1
-        avail = used << 1
-        depth += 1
-        used = 0
-    return a
-
-
-def flatten(bits, limit):
-    """Limit code lengths (sorted longest first) to `limit` bits keeping the code complete
-    (flatten(): flatten.c:5-63).  Returns False if that cannot be done."""
-    n = len(bits)
-    if n == 0 or bits[0] <= limit:
-        return True
-    if (1 << limit) < n:
-        return False
-    mx = bits[0]
-    k, debt, to = 0, 0, 1 << (mx - limit)
-    while True:
-        debt += to - (1 << (mx - bits[k]))
-        bits[k] = limit
-        k += 1
-        if not (k < n and bits[k] > limit):
-            break
-    debt >>= mx - limit
-    while k < n and bits[k] == limit:
-        k += 1
-    while k < n:
-        pay = (1 << (limit - bits[k])) - 1
-        bits[k] = limit
-        k += 1
-        debt -= pay
-        if debt <= 0:
-            break
-    if debt == 0:
-        return True
-    k = n
-    while k and bits[k - 1] == 1:
-        k -= 1
-    while k:
-        spend = 1 << (limit - bits[k - 1])
-        if debt + spend > 0:
-            k -= 1
-            continue
-        k -= 1
-        bits[k] -= 1
-        debt += spend
-        if debt == 0:
-            break
-    return debt == 0
-
-
-def write_simple(w, kind, bits, syms):
-    """simple(): brogen.cc:298-338."""
+def simple_code(w, kind, abits, syms):
+    """`s`: a simple prefix code (RFC 7932 section 3.4; what brogen.cc:298-338 writes): NSYM - 1, the symbols,
+    the tree-select bit for four symbols.  Returns {symbol: (code, length)}: the lengths are fixed by the kind,
+    and within one length the decoder takes the symbols in rising order."""
     num = 4 if kind == 5 else kind
-    w.put(2, 1)
-    w.put(2, num - 1)
-    for s in syms[:num]:
-        w.put(bits, s)
-    if num >= 4:
-        w.put(1, kind - 4)
-    s = list(syms)
+    w.bits(2, 1)
+    w.bits(2, num - 1)
+    for v in syms[:num]:
+        w.bits(abits, v)
+    if num == 4:
+        w.bits(1, kind - 4)
+    shape = {1: [0], 2: [1, 1], 3: [1, 2, 2], 4: [2, 2, 2, 2], 5: [1, 2, 3, 3]}[kind]
     if kind == 1:
-        return canonical([1, 0, 0, 0], s)
-    if kind == 2:
-        return canonical([0, 2, 0, 0], sorted(s))
-    if kind == 3:
-        return canonical([0, 1, 2, 0], [s[0]] + sorted(s[1:3]))
-    if kind == 4:
-        return canonical([0, 0, 4, 0], sorted(s))
-    return canonical([0, 1, 1, 2], s[:2] + sorted(s[2:4]))
+        return {syms[0]: (0, 0)}
+    return canonical(dict(zip(syms, shape)))
 
 
-def write_complex(w, desc):
-    """complex(): brogen.cc:346-518.  desc: [(length, symbol)], a complete code."""
-    desc = sorted(desc, key=lambda d: d[1])
-    inst = []  # (instruction 0..17, extra bits value)
-    state = {"rep": 0, "len": 0, "last": 8}
-
-    def emit():
-        while state["rep"]:
-            if state["rep"] < 3 or state["len"] != state["last"]:
-                inst.append((state["len"], 0))
-                state["last"] = state["len"]
-                state["rep"] -= 1
-            if state["rep"] >= 3:
-                dig = []
-                state["rep"] -= 2
-                while True:
-                    state["rep"] -= 1
-                    dig.append(state["rep"] & 3)
-                    state["rep"] >>= 2
-                    if not state["rep"]:
-                        break
-                for d in reversed(dig):
-                    inst.append((16, d))
-    nxt = 0
+def complex_code(w, desc):
+    """`c`: a complex prefix code from [(length, symbol)] (a complete code; what brogen.cc:346-518 writes).  The
+    descriptor is laid out by brosynth.write_lengths: run-length symbols where a run is long enough, a
+    length-limited Huffman code over the symbols of that sequence.  Returns {symbol: (code, length)}."""
+    lens = [0] * (max(sym for _, sym in desc) + 1)
     for length, sym in desc:
-        if nxt < sym:
-            emit()
-            zeros = sym - nxt
-            if zeros < 3:
-                inst.extend([(0, 0)] * zeros)
-            else:
-                dig = []
-                zeros -= 2
-                while True:
-                    zeros -= 1
-                    dig.append(zeros & 7)
-                    zeros >>= 3
-                    if not zeros:
-                        break
-                for d in reversed(dig):
-                    inst.append((17, d))
-            nxt = sym
-        if state["rep"] and state["len"] != length:
-            emit()
-        state["len"] = length
-        state["rep"] += 1
-        nxt += 1
-    emit()
-    freq = [0] * 18
-    for i, _ in inst:
-        freq[i] += 1
-    idesc = [[freq[i], i] for i in range(18) if freq[i]]  # [frequency -> length, instruction]
-    if len(idesc) > 1:
-        idesc.sort()
-        lens = huffman_lengths([d[0] for d in idesc])
-        assert flatten(lens, 5)
-        for d, l in zip(idesc, lens):
-            d[0] = l
-        idesc.sort()
-        count = [0] * 6
-        for l, _ in idesc:
-            count[l] += 1
-        icode = canonical(count, [i for _, i in idesc])
-    else:
-        idesc[0][0] = 3
-        icode = {idesc[0][1]: (0, 0)}
-    order = [4, 0, 1, 2, 3, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 8, 6]
-    lst = [0] * 18
-    for l, i in idesc:
-        lst[order[i]] = l
-    start = 0 if (lst[0] or lst[1]) else 2 if lst[2] else 3
-    w.put(2, start)
-    end = 17
-    if len(idesc) > 1:
-        while end and lst[end] == 0:
-            end -= 1
-    lencode = canonical([0, 0, 3, 1, 2], [0, 3, 4, 2, 1, 5])
-    for k in range(start, end + 1):
-        w.put(*lencode[lst[k]])
-    for i, x in inst:
-        w.put(*icode[i])
-        if i > 15:
-            w.put(i - 14, x)
-    desc = sorted(desc)
-    count = [0] * 16
-    for l, _ in desc:
-        count[l] += 1
-    return canonical(count, [s for _, s in desc])
+        lens[sym] = length
+    write_lengths(w, lens, rle=True, hskip_pref=3)
+    return canonical({sym: length for length, sym in desc if length})
 
 
 _ESC = {"a": 7, "b": 8, "f": 12, "n": 10, "r": 13, "t": 9, "v": 11}
@@ -332,7 +143,7 @@ def _tokens(text):
 
 
 def brogen(text):
-    w = Bits()
+    w = Out()
     codes = {}
     last = 0
 
@@ -347,18 +158,18 @@ def brogen(text):
             p = parm(vals, 1, 0, 63, "bits count")
             q = parm(vals, 0, 0, (1 << (p or 0)) - 1, "bits value")
             if p is not None and q is not None:
-                w.put(p, q)
+                w.bits(p, q)
         elif cmd == "bound":
             p = parm(vals, 0, 0, 127, "bound fill bits")
-            w.flush(p or 0)
+            w.to_boundary(p or 0)
         elif cmd == "w":
             p = parm(vals, 16, 10, 24, "wbits")
             if p is not None:
-                w.put(1, 0 if p == 16 else 1)
+                w.bits(1, 0 if p == 16 else 1)
                 if p != 16:
-                    w.put(3, 0 if p < 18 else p - 17)
+                    w.bits(3, 0 if p < 18 else p - 17)
                     if p < 18:
-                        w.put(3, 0 if p == 17 else p - 8)
+                        w.bits(3, 0 if p == 17 else p - 8)
         elif cmd == "last":
             v = parm(vals, 1, 0, 1, "last")
             last = last if v is None else v
@@ -370,52 +181,51 @@ def brogen(text):
                 sys.stderr.write("last block cannot be uncompressed\n")
                 continue
             if cmd == "m" and last:
-                w.put(2, 1)
+                w.bits(2, 1)
             else:
-                w.put(1, 0)
+                w.bits(1, 0)
             q = 6 if p > (1 << 20) else 5 if p > (1 << 16) else 4
-            w.put(2, q - 4)
-            w.put(q << 2, p - 1)
+            w.bits(2, q - 4)
+            w.bits(q << 2, p - 1)
             if cmd == "u":
-                w.put(1, 1)
+                w.bits(1, 1)
             elif not last:
-                w.put(1, 0)
+                w.bits(1, 0)
         elif cmd == "e":
             p = parm(vals, 0, -1, 1 << 24, "meta-data length")
             if p is None:
                 continue
             if last or p == -1:
                 if p == -1:
-                    w.put(2, 3)
+                    w.bits(2, 3)
                     continue
-                w.put(2, 1)
+                w.bits(2, 1)
             else:
-                w.put(1, 0)
-            w.put(2, 3)
-            w.put(1, 0)
+                w.bits(1, 0)
+            w.bits(2, 3)
+            w.bits(1, 0)
             q = 0 if p <= 0 else 1 if p <= (1 << 8) else 2 if p <= (1 << 16) else 3
-            w.put(2, q)
-            w.put(q << 3, p - 1)
+            w.bits(2, q)
+            w.bits(q << 3, p - 1)
         elif cmd == "lit":
-            w.flush()
-            w.out.extend(v & 255 for v in vals)
+            w.raw(vals)
             vals.clear()
         elif cmd == "types":
             p = parm(vals, 1, 1, 256, "number of block types")
             if p is None:
                 continue
-            w.put(1, 1 if p > 1 else 0)
+            w.bits(1, 1 if p > 1 else 0)
             if p > 1:
                 q = 0
                 while (1 << (q + 1)) < p:
                     q += 1
-                w.put(3, q)
+                w.bits(3, q)
                 if q:
-                    w.put(q, p - 1 - (1 << q))
+                    w.bits(q, p - 1 - (1 << q))
         elif cmd == "len":
             p = parm(vals, 0, 0, 5, "code length")
             if p is not None:
-                w.put(*[(2, 0), (4, 7), (3, 3), (2, 2), (2, 1), (4, 15)][p])
+                w.bits(*LEN_BITS[p])
         elif cmd == "s":
             ident = parm(vals, 0, -(1 << 63), 1 << 63, "id")
             kind = parm(vals, 0, 1, 5, "simple code type")
@@ -429,7 +239,7 @@ def brogen(text):
                 sys.stderr.write("invalid symbol values -- skipping\n")
                 vals.clear()
                 continue
-            codes[ident] = write_simple(w, kind, bits, list(vals))
+            codes[ident] = simple_code(w, kind, bits, list(vals))
             vals.clear()
         elif cmd == "c":
             ident = parm(vals, 0, -(1 << 63), 1 << 63, "id")
@@ -447,13 +257,13 @@ def brogen(text):
             if sum(1 << (15 - l) for l, _ in desc) != 1 << 15:
                 sys.stderr.write("incomplete code -- skipping\n")
                 continue
-            codes[ident] = write_complex(w, desc)
+            codes[ident] = complex_code(w, desc)
         elif cmd == "p":
             ident = parm(vals, 0, -(1 << 63), 1 << 63, "id")
             if ident in codes:
                 for s in vals:
                     if s in codes[ident]:
-                        w.put(*codes[ident][s])
+                        w.word(codes[ident][s])
                     else:
                         sys.stderr.write("symbol %d not found in code %d\n" % (s, ident))
             else:
@@ -465,8 +275,8 @@ def brogen(text):
             sys.stderr.write("! unknown command: %s\n" % cmd)
         if vals:
             sys.stderr.write("%d extraneous parameters for %s ignored\n" % (len(vals), cmd))
-    w.flush()
-    return bytes(w.out)
+    w.to_boundary()
+    return w.bytes()
 
 
 if __name__ == "__main__":

@@ -177,70 +177,76 @@ class Code:
             if shape >= 4:
                 bw.put(shape - 4, 1)
             return
-        lens = [self.lens.get(s, 0) for s in range(num)]
-        while lens and lens[-1] == 0:
-            lens.pop()
-        # code-length symbols, optionally with the run codes 16 (repeat) and 17 (zeros)
-        seq = []  # (symbol, extra value, extra bits)
-        if not self.rle:
-            seq = [(l, 0, 0) for l in lens]
-        else:
-            i = 0
-            prev = 8
-            while i < len(lens):
-                l = lens[i]
-                j = i
-                while j < len(lens) and lens[j] == l:
-                    j += 1
-                run = j - i
-                if l == 0 and run >= 3:
-                    seq += zero_runs(run)
-                    i = j
-                    continue
-                if l != 0 and l == prev and run >= 3:
-                    seq += repeat_runs(run)
-                    i = j
-                    continue
-                if l != 0 and run >= 4:
-                    seq.append((l, 0, 0))
-                    seq += repeat_runs(run - 1)
-                    prev = l
-                    i = j
-                    continue
+        write_lengths(bw, [self.lens.get(s, 0) for s in range(num)], self.rle, self.hskip_pref)
+
+
+def write_lengths(bw, lens, rle=True, hskip_pref=3):
+    """a complex prefix code's descriptor (yeast.c:430-530): the code length code, then the lengths of the symbols
+    0 .. last used, with runs as codes 16 and 17 when rle is set; hskip_pref: the largest HSKIP to use when it fits"""
+    lens = list(lens)
+    while lens and lens[-1] == 0:
+        lens.pop()
+    # code-length symbols, optionally with the run codes 16 (repeat) and 17 (zeros)
+    seq = []  # (symbol, extra value, extra bits)
+    if not rle:
+        seq = [(l, 0, 0) for l in lens]
+    else:
+        i = 0
+        prev = 8
+        while i < len(lens):
+            l = lens[i]
+            j = i
+            while j < len(lens) and lens[j] == l:
+                j += 1
+            run = j - i
+            if l == 0 and run >= 3:
+                seq += zero_runs(run)
+                i = j
+                continue
+            if l != 0 and l == prev and run >= 3:
+                seq += repeat_runs(run)
+                i = j
+                continue
+            if l != 0 and run >= 4:
                 seq.append((l, 0, 0))
-                if l:
-                    prev = l
-                i += 1
-        hist = {}
-        for s, _, _ in seq:
-            hist[s] = hist.get(s, 0) + 1
-        if len(hist) == 1:
-            only = next(iter(hist))
-            cl_lens = {only: 3}  # single-symbol code-length code: zero bits per symbol (yeast.c:456-459)
-            cl_codes = {only: (0, 0)}
-        else:
-            cl_lens = limited_lengths(hist, 5)
-            cl_codes = canonical(cl_lens)
-        hskip = 0
-        for h in (3, 2):
-            if h <= self.hskip_pref and all(cl_lens.get(CL_ORDER[k], 0) == 0 for k in range(h)):
-                hskip = h
-                break
-        bw.put(hskip, 2)
-        space = 32
-        for k in range(hskip, 18):
-            l = cl_lens.get(CL_ORDER[k], 0)
-            c, n = CL_VLC[l]
-            bw.code(c, n)
+                seq += repeat_runs(run - 1)
+                prev = l
+                i = j
+                continue
+            seq.append((l, 0, 0))
             if l:
-                space -= 32 >> l
-                if space <= 0:
-                    break
-        for s, ev, eb in seq:
-            c, l = cl_codes[s]
-            bw.code(c, l)
-            if eb:
-                bw.put(ev, eb)
+                prev = l
+            i += 1
+    hist = {}
+    for s, _, _ in seq:
+        hist[s] = hist.get(s, 0) + 1
+    if len(hist) == 1:
+        only = next(iter(hist))
+        cl_lens = {only: 3}  # single-symbol code-length code: zero bits per symbol (yeast.c:456-459)
+        cl_codes = {only: (0, 0)}
+    else:
+        cl_lens = limited_lengths(hist, 5)
+        cl_codes = canonical(cl_lens)
+    hskip = 0
+    for h in (3, 2):
+        if h <= hskip_pref and all(cl_lens.get(CL_ORDER[k], 0) == 0 for k in range(h)):
+            hskip = h
+            break
+    bw.put(hskip, 2)
+    space = 32
+    for k in range(hskip, 18):
+        l = cl_lens.get(CL_ORDER[k], 0)
+        c, n = CL_VLC[l]
+        bw.code(c, n)
+        if l:
+            space -= 32 >> l
+            if space <= 0:
+                break
+    for s, ev, eb in seq:
+        c, l = cl_codes[s]
+        bw.code(c, l)
+        if eb:
+            bw.put(ev, eb)
 
 
 def repeat_runs(run):
