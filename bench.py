@@ -117,7 +117,7 @@ def kernel_label(n, lanes):
     if lanes == 65:
         return "k_decode_wave"
     if lanes == 1:
-        half = int(os.environ.get("YEAST_HALF", "0" if n >= 131072 else "1"))
+        half = int(os.environ.get("YEAST_HALF", "1"))
         return "k_decode_lean<%d>" % {0: 64, 1: 32, 2: 16}.get(half, 32)
     return "k_decode<%d>" % lanes
 

@@ -428,10 +428,10 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     const bool flat = lanes == 1;
     /* one stream per lane: half-filled wavefronts (two per SIMD, the default), full ones (0) or
        quarter-filled ones (2) */
-    /* up to 65,536 streams per 256 CUs fit half-filled wavefronts, two per SIMD (one round); twice
-       that and more run in full wavefronts, two per SIMD (116 ms against 127 ms at 131,072 streams) */
-    const bool many = n >= (size_t)d.cus * 512;
-    const int half = flat ? env_int("YEAST_HALF", many ? 0 : 1) : 0;
+    /* half-filled wavefronts, two per SIMD: 65,536 streams per 256 CUs are one round; larger batches take
+       further rounds, the wavefronts that finish early picking up the shorter streams (107 ms against 116 ms
+       in full wavefronts at 131,072 streams, 213 against 223 at 262,144) */
+    const int half = flat ? env_int("YEAST_HALF", 1) : 0;
     unsigned per_block = 256u / (unsigned)lanes / (half == 2 ? 4u : half ? 2u : 1u);
     unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : 2) : 4);
     size_t want_blocks = (n + per_block - 1) / per_block;
