@@ -307,7 +307,7 @@ static const char *const KNOB_NAMES[] = {"YEAST_LANES", "YEAST_WAVES_PER_CU", "Y
                                          "YEAST_ROOT_IAC", "YEAST_ROOT_DIST", "YEAST_HALF", "YEAST_BLOCKS_PER_CU",
                                          "YEAST_WS_KB", "YEAST_LEAN_ROOT_LIT", "YEAST_LEAN_ROOT_IAC",
                                          "YEAST_LEAN_ROOT_DIST", "YEAST_SORT", "YEAST_DEBUG", "YEAST_HOST_THREADS",
-                                         "YEAST_FORCE_LANES", "YEAST_PRIO"};
+                                         "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB"};
 enum { KNOBS = sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]) };
 static int g_knob_val[KNOBS];
 static bool g_knob_set[KNOBS];
@@ -661,8 +661,26 @@ template <class F> static void host_parallel(size_t n, u64 bytes, F fn)
 
 /* Decode n host streams; fills rec[] and, for cmp == 0, out[i] (malloc'd).
    expected/have: compare mode inputs (cmp != 0, n == 1 in practice). */
+static int run_host_batch_impl(size_t n, void const *const *src, const size_t *len, std::vector<ys_record> &rec,
+                               void **out, unsigned check_kind, int cmp, const void *expected, size_t have);
+
+/* On failure nothing is left with the caller: copies in flight are waited for, the buffers handed out so far freed. */
 static int run_host_batch(size_t n, void const *const *src, const size_t *len, std::vector<ys_record> &rec,
                           void **out, unsigned check_kind, int cmp, const void *expected, size_t have)
+{
+    int e = run_host_batch_impl(n, src, len, rec, out, check_kind, cmp, expected, have);
+    if (e && out) {
+        (void)hipStreamSynchronize(nullptr);
+        for (size_t i = 0; i < n; i++) {
+            free(out[i]);
+            out[i] = nullptr;
+        }
+    }
+    return e;
+}
+
+static int run_host_batch_impl(size_t n, void const *const *src, const size_t *len, std::vector<ys_record> &rec,
+                               void **out, unsigned check_kind, int cmp, const void *expected, size_t have)
 {
     Device *dp;
     if (device_get(&dp))
@@ -672,7 +690,7 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
     rec.assign(n, ys_record{});
     std::vector<u64> soff(n + 1), doff(n + 1);
     std::vector<size_t> todo(n);
-    std::vector<u64> cap(n);
+    std::vector<u64> cap(n), need(n, 0); /* need: what a stream was last found to need at least */
     for (size_t i = 0; i < n; i++) {
         todo[i] = i;
         if (cmp)
@@ -694,7 +712,51 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
     int lanes = env_int("YEAST_FORCE_LANES", 0); /* enqueue() chooses by n; the override is for the tests */
 
     while (!todo.empty()) {
+        /* One pass takes as many of the streams still to do as fit a share of the device memory that is free: the
+           capacities come from unverified headers (up to 16 MiB per meta-block), and one arena for a whole batch of
+           such claims may not exist.  A stream that does not fit by itself is out of memory (code 1), as it would
+           be for the reference's realloc(); the others are decoded. */
         size_t m = todo.size();
+        std::vector<size_t> later;
+        if (!cmp) {
+            size_t freeb = 0, totalb = 0;
+            u64 budget = (u64)16 << 30;
+            if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
+                u64 b = ((u64)freeb + d.dst.cap) / 5 * 3;
+                budget = b < budget ? b : budget;
+            }
+            if (budget < ((u64)64 << 20))
+                budget = (u64)64 << 20;
+            if (env_int("YEAST_HOST_BUDGET_MB", 0) > 0) /* for the tests */
+                budget = (u64)env_int("YEAST_HOST_BUDGET_MB", 0) << 20;
+            u64 sum = 0;
+            size_t take = 0;
+            std::vector<size_t> now;
+            for (size_t k = 0; k < m; k++) {
+                size_t i = todo[k];
+                u64 c = round_up(cap[i], 16);
+                if (c > budget && need[i] && need[i] <= (budget & ~(u64)15)) /* the doubling overshot: what fits */
+                    c = cap[i] = budget & ~(u64)15;
+                if (c > budget) { /* not even alone */
+                    rec[i] = ys_record{};
+                    rec[i].rc = YS_NOMEM;
+                    continue;
+                }
+                if (sum + c > budget) {
+                    later.push_back(i);
+                    continue;
+                }
+                sum += c;
+                now.push_back(i);
+                take++;
+            }
+            todo.swap(now);
+            m = take;
+            if (m == 0) {
+                todo.swap(later);
+                continue;
+            }
+        }
         u64 stot = 0, dtot = 0;
         for (size_t k = 0; k < m; k++) {
             soff[k] = stot;
@@ -748,9 +810,9 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
         for (size_t k = 0; k < m; k++) {
             size_t i = todo[k];
             if (r[k].rc == YS_CAPACITY) {
-                u64 need = r[k].check;
+                need[i] = r[k].check;
                 u64 c2 = cap[i] * 2;
-                cap[i] = need > c2 ? need : c2;
+                cap[i] = need[i] > c2 ? need[i] : c2;
                 again.push_back(i);
                 continue;
             }
@@ -786,6 +848,7 @@ static int run_host_batch(size_t n, void const *const *src, const size_t *len, s
                 return 1;
         }
         HIPCK(hipStreamSynchronize(st));
+        again.insert(again.end(), later.begin(), later.end());
         todo.swap(again);
     }
     return 0;

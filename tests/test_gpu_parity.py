@@ -158,6 +158,26 @@ def test_large_streams_inside_a_large_batch():
             assert r[0] == 0 and r[1] == w and r[3] == len(batch[i]), i
 
 
+def test_host_batch_in_passes_under_a_memory_budget(monkeypatch):
+    # a host batch larger than the share of device memory it may take goes in several passes with the same
+    # results; a stream that does not fit the budget by itself is out of memory (code 1) and the others decode
+    meta, streams = H.packed_streams("cfg2_streams")
+    m5, s5 = H.packed_streams("cfg5_streams")
+    monkeypatch.setenv("YEAST_HOST_BUDGET_MB", "8")
+    batch = list(streams) + [s5[0]] + list(streams[:40])  # ~27 MB of output in all; s5[0] needs 18 MB
+    res = ba.yeast_batch(batch, ba.CHECK_XXH64)
+    for i, r in enumerate(res):
+        if i == len(streams):
+            assert r[0] == 1 and r[2] == 0, r[:1]
+            continue
+        m = meta["streams"][i if i < len(streams) else i - len(streams) - 1]
+        assert (r[0], r[2], r[3]) == (0, m["got"], m["len"]), i
+        assert "%016x" % r[4] == m["xxh64"], i
+    monkeypatch.setenv("YEAST_HOST_BUDGET_MB", "32")
+    r = ba.yeast_batch([s5[0]], ba.CHECK_XXH64)[0]
+    assert (r[0], r[2]) == (0, m5["streams"][0]["got"]) and "%016x" % r[4] == m5["streams"][0]["xxh64"]
+
+
 @pytest.mark.parametrize("lanes", [65, 64, 16, 8, 1, -1, -2, -3])
 def test_cfg2_batch_every_group_width(lanes, monkeypatch):
     meta, streams = H.packed_streams("cfg2_streams")
