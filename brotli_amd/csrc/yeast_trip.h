@@ -342,7 +342,11 @@ NOINL TripOut run_trip_fn(TripIn a)
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
         pwait += tb_ - ta_;
 #endif
-        e = asked ? wl->ent[slot] & 0xffff : e; /* a stream in the middle of a copy keeps the entry it holds */
+        {
+            u32 en = wl->ent[slot];
+            asm volatile("" : "+v"(en)); /* read by every lane: a branch around the read costs more than the read */
+            e = asked ? en & 0xffff : e; /* a stream in the middle of a copy keeps the entry it holds */
+        }
         TMARK(0);
         const bool hold = crem != 0; /* a copy of several pieces is going on: the entry waits */
         const bool active = st <= YT_BC && !hold;
