@@ -113,7 +113,7 @@ def measured_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
 def kernel_label(n, lanes):
     """The decode kernel the library's dispatcher picks (yeast_host.cpp enqueue())."""
     env = int(os.environ.get("YEAST_LANES", "0"))
-    lanes = lanes or env or (1 if n >= 8192 else 65)
+    lanes = lanes or env or (1 if n >= 6144 else 65)
     if lanes == 65:
         return "k_decode_wave"
     if lanes == 1:
@@ -266,7 +266,7 @@ def main():
                                   len(distinct), {0: "no", 1: "CRC-32C", 2: "XXH32", 3: "XXH64"}[args.check],
                                   " + RCCL all-gather of records" if world > 1 else ""),
                    "streams_per_gpu": n, "order": args.order, "out_bytes_per_gpu": out_bytes, "in_bytes_per_gpu": in_bytes,
-                   "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "0")) or (1 if n >= 8192 else 65),
+                   "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "0")) or (1 if n >= 6144 else 65),
                    "parallelism": "%d independent shards" % world},
         "roofline": {"bound": "hbm", "kernel": kernel_label(n, args.lanes), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
