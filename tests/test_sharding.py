@@ -57,3 +57,25 @@ def test_all_gather_records_gloo_world2(counts):
         p.join(60)
     want = bytes([1]) * (counts[0] * 32) + bytes([2]) * (counts[1] * 32)
     assert got[0] == want and got[1] == want
+
+
+def test_bench_strong_scaling_shards_cover_the_batch_once():
+    # bench.py --scaling strong: every rank builds the same 65,536-stream order and takes its contiguous shard,
+    # cut by compressed bytes; the shards tile the batch, the record sizes handed to the all-gather match them
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    meta, distinct = bench.load_distinct()
+    full = bench.build_order(65536, len(distinct), 0x5EED, "shuffled")
+    assert sorted(np.bincount(full, minlength=len(distinct))) == [256] * 256
+    weights = [len(distinct[j]) for j in full]
+    for world in (1, 2, 4, 8):
+        shards = balanced_shards(weights, world)
+        assert shards[0][0] == 0 and shards[-1][1] == 65536
+        assert all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+        sums = [sum(weights[a:b]) for a, b in shards]
+        assert max(sums) - min(sums) <= 2 * max(weights)
+    # the label in the bench line follows the dispatcher's rule (include/yeast_batch.h: lanes_per_stream 0)
+    for k in ("YEAST_LANES", "YEAST_HALF"):
+        os.environ.pop(k, None)
+    assert bench.kernel_label(65536, 0) == "k_decode_lean<32>" and bench.kernel_label(6144, 0) == "k_decode_lean<32>"
+    assert bench.kernel_label(6143, 0) == "k_decode_wave" and bench.kernel_label(100, 64) == "k_decode<64>"
