@@ -529,6 +529,15 @@ NOINL TripOut run_trip_fn(TripIn a)
         request(st <= YT_BC && (want || is_link || (active && st >= YT_BT)));
 
         TMARK(5);
+#ifdef YT_EXP_PAD /* measurement build: what an instruction costs (dependent vector adds, placed under the loads) */
+        {
+            u32 padv = st;
+#pragma unroll
+            for (int i = 0; i < YT_EXP_PAD; i++)
+                asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv));
+            asm volatile("" :: "v"(padv));
+        }
+#endif
         /* ================= 4. under those loads: the copy that begins or goes on, its next piece ================= */
         const u32 got = (u32)(uintptr_t)op - out_lo;
         u32 m = crem < 16 ? crem : 16;
