@@ -1,7 +1,7 @@
 /*
  * yeast_lane.hip -- MI355X (gfx950) batch Brotli decode, one stream per lane: the kernel of large
  * batches (BASELINE config 2).  The per-stream decoder is yeast_stream.h, its command loop
- * yeast_lean.h; this file holds the kernel, the kernel that expands the static dictionary, and
+ * yeast_trip.h; this file holds the kernel, the kernel that expands the static dictionary, and
  * their launchers.
  */
 #include <hip/hip_runtime.h>
@@ -18,19 +18,11 @@
 template <int S>
 __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) void k_decode_lean(ys_params p)
 {
-#ifdef YS_OLD_LOOP
-    __shared__ Shared sh;
-    __shared__ LeanLds<S> wlds[4];
-    shared_fill(sh, p.xforms, p.xdict_base);
-    const Shared *shp = &sh;
-    const TripShared *tsp = nullptr;
-#else
     __shared__ TripShared tsh;
     __shared__ TripLds<S> wlds[4];
     trip_shared_fill(tsh, p.xforms, p.xdict_base);
     const Shared *shp = nullptr; /* the header parser of the batch kernel reads none of it */
     const TripShared *tsp = &tsh;
-#endif
     u32 lane = threadIdx.x;
     u32 wave = (blockIdx.x * blockDim.x + lane) >> 6;
     u32 slot = lane & 63;

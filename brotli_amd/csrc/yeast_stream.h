@@ -496,7 +496,7 @@ DEV void group_sync_mem() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"
 
 /* ------------------------------------------------ batch kernel command loop */
 
-/* what the meta-block header hands to the command loop of the batch kernel (yeast_lean.h) */
+/* what the meta-block header hands to the command loop of the batch kernel (yeast_trip.h) */
 struct FlatEnv {
     const u32 *itab, *dtab, *lit_tab;
     const u8 *mode;
@@ -504,12 +504,8 @@ struct FlatEnv {
     bool ctx;
 };
 
-#ifdef YS_OLD_LOOP
-#include "yeast_lean.h"
-#else
 #define YS_XD_LENS 21 /* word lengths 4..24 */
 #include "yeast_trip.h"
-#endif
 
 /* ------------------------------------------------------------- meta-block */
 
@@ -786,18 +782,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
         fe.offD0 = (u32)((const u8 *)tD0 - c.ws);
         fe.cur_mode = cur_mode;
         fe.ctx = ctx;
-        /* meta-blocks without block switching (the usual case for short streams) run a loop that
-           carries none of that machinery; the choice is made for the whole wavefront so the
-           streams stay in one loop */
-#ifdef YS_OLD_LOOP
-        bool simple = c.L.num == 1 && c.I.num == 1 && c.D.num == 1;
-        if (__all(simple))
-            run_lean<FLAT, true>(c, mlen, fe);
-        else
-            run_lean<FLAT, false>(c, mlen, fe);
-#else
         run_trip<FLAT>(c, mlen, fe);
-#endif
     }
     if (!r.rc && last && tail_nonzero(r))
         rd_fail(r, YS_INVALID); /* :1305 */

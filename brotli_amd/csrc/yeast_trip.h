@@ -93,7 +93,6 @@ DEV u32x4 sld128(const u8 *base, u32 off) /* 4-byte aligned */
 #define YT_DIST 2u
 #define YT_BT 3u   /* block-switch type symbol */
 #define YT_BC 4u   /* block-switch count symbol */
-#define YT_COPY 5u /* a copy of more than one piece in progress: nothing to decode */
 #define YT_END 6u
 
 /* What the loop takes from the stream's state and hands back.  The loop is an out-of-line function so that it
