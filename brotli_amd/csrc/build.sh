@@ -13,7 +13,9 @@ $HIPCC $FLAGS -c yeast_check.hip -o yeast_check.o &
 P2=$!
 $HIPCC $FLAGS -c yeast_wave.hip -o yeast_wave.o ${YEAST_EXTRA_FLAGS} &
 P4=$!
-$HIPCC $FLAGS -c yeast_lane.hip -o yeast_lane.o ${YEAST_EXTRA_FLAGS} &
+# the batch kernel's loop is bound by the latency of dependent instructions of one wavefront: schedule it for
+# instruction-level parallelism (43.4 -> 42.1 ms at 8,192 streams; the full batch within noise)
+$HIPCC $FLAGS -mllvm -amdgpu-sched-strategy=max-ilp -c yeast_lane.hip -o yeast_lane.o ${YEAST_EXTRA_FLAGS} &
 P5=$!
 $HIPCC $FLAGS -c yeast_host.cpp -o yeast_host.o &
 P3=$!
