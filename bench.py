@@ -277,7 +277,9 @@ def main():
     series = os.path.join(ROOT, "profiles", "r02", "stream_series.json")
     if os.path.exists(series):
         # single-GPU kernel time over batch sizes: what one shard of a strong-scaling run costs
-        line["strong_scaling_floor"] = json.load(open(series))
+        fl = json.load(open(series))
+        line["strong_scaling_floor"] = {"what": fl["what"], "source": "profiles/r02/stream_series.json",
+                                        "kernel_ms_by_streams": {str(r["streams"]): r["kernel_ms"] for r in fl["rows"]}}
     if rank == 0 and world == 1 and args.cpu_sample:
         # threads: this job's CPU share (OMP_NUM_THREADS is set to it on the GPU box, where os.cpu_count()
         # counts the whole machine); host_cpus says what the machine has
