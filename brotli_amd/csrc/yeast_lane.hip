@@ -171,7 +171,8 @@ static int launch_lean_t(const ys_params &p, u32 streams, hipStream_t st)
 /* streams = resident streams (each owns one workspace slot); half != 0: half-filled wavefronts */
 extern "C" int ysl_launch(const ys_params *p, int half, unsigned streams, void *stream)
 {
-    if (half == 2) /* quarter-filled wavefronts, four per SIMD */
+    if (half == 2) /* quarter-filled wavefronts (a test and measurement shape: the kernel needs ~196 registers with its
+                      out-of-line header code, so two wavefronts per SIMD are resident whatever the shape) */
         return launch_lean_t<16>(*p, streams, (hipStream_t)stream);
     return half ? launch_lean_t<32>(*p, streams, (hipStream_t)stream) : launch_lean_t<64>(*p, streams, (hipStream_t)stream);
 }
