@@ -158,6 +158,24 @@ def test_large_streams_inside_a_large_batch():
             assert r[0] == 0 and r[1] == w and r[3] == len(batch[i]), i
 
 
+@pytest.mark.parametrize("lanes", KERNELS)
+def test_randomly_assembled_streams(lanes, monkeypatch):
+    # 400 streams whose features are mixed by a seeded choice (tests/random_plans.py): several meta-blocks, context
+    # modes and maps, NPOSTFIX/NDIRECT, block switching, dictionary words, ring and implicit distances, overlapping
+    # and long copies; through every kernel, against the CPU restatement, bit for bit
+    import random_plans as R
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    ss = R.streams(400, 20261111)
+    res = ba.yeast_batch([s for s, _ in ss], ba.CHECK_CRC32C)
+    o = H.oracle()
+    for i, ((s, want), r) in enumerate(zip(ss, res)):
+        rc, got, used, out = H.oracle_yeast(s)
+        assert (rc, out) == (0, want), i
+        assert (r[0], r[2], r[3]) == (rc, got, used), i
+        assert r[1] == out, i
+        assert r[4] == o.oracle_crc32c(0, out, len(out)), i
+
+
 def test_host_batch_in_passes_under_a_memory_budget(monkeypatch):
     # a host batch larger than the share of device memory it may take goes in several passes with the same
     # results; a stream that does not fit the budget by itself is out of memory (code 1) and the others decode

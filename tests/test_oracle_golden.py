@@ -263,3 +263,15 @@ def test_restatement_under_address_and_ub_sanitizers(tmp_path):
             assert int(b) == w[2], (k, line, w)
         if w[3] is not None and w[0] == 0:
             assert x == w[3], (k, line, w)
+
+
+def test_randomly_assembled_streams_against_the_reference():
+    # the streams of the GPU tier's random test (tests/random_plans.py), another seed: the restatement and the real
+    # reference decoder agree on every one (where oracle/_ref is built), and both with the synthesiser
+    import random_plans as R
+    ref = H.reference()
+    for i, (s, want) in enumerate(R.streams(150, 4711)):
+        got = H.oracle_yeast(s)
+        assert (got[0], got[3], got[2]) == (0, want, len(s)), i
+        if ref is not None:
+            assert H.run_yeast(ref.yeast, s) == got, i
