@@ -174,6 +174,20 @@ def test_randomly_assembled_streams(lanes, monkeypatch):
         assert (r[0], r[2], r[3]) == (rc, got, used), i
         assert r[1] == out, i
         assert r[4] == o.oracle_crc32c(0, out, len(out)), i
+    # the same streams damaged (bit flips, cuts): same code, same progress, same partial output
+    rnd = random.Random(5 + lanes)
+    hurt = []
+    for s, _ in ss[:250]:
+        b = bytearray(s)
+        if rnd.random() < 0.3:
+            b = b[:rnd.randrange(1, len(b) + 1)]
+        for _ in range(rnd.randrange(1, 4)):
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        hurt.append(bytes(b))
+    for i, (s, r) in enumerate(zip(hurt, ba.yeast_batch(hurt))):
+        rc, got, used, out = H.oracle_yeast(s)
+        assert (r[0], r[2], r[3]) == (rc, got, used), i
+        assert r[1] == out, i
 
 
 def test_host_batch_in_passes_under_a_memory_budget(monkeypatch):
