@@ -325,13 +325,24 @@ DEV void build_table(Hdr &h, const Cnt16 &count, u32 root)
         h.tab = YS_WS_ARENA;
         return;
     }
-    u32 si = 0;
+    u32 nsyms = 0;
+    for (u32 l = 1; l <= 15; l++)
+        nsyms += cnt_get(count, l);
     u32 grp = root + 1; /* depth group of the current prefix (prefixes only grow) */
     u32 cur_c = 0xffffffffu, cur_sb = 0;
-    for (u32 len = 1; len <= maxlen; len++) {
-        u32 n = cnt_get(count, len), code = cnt_get(first, len);
-        for (u32 k = 0; k < n; k++, si++, code++) {
-            u32 s = gld16(sorted + si);
+    u32 len = 0, left_len = 0, code = 0;
+    /* the symbols come in canonical order, eight to a load (one load per symbol is one memory round trip per symbol) */
+    for (u32 s0 = 0; s0 < nsyms; s0 += 8) {
+        const u32x4 sv = gld128u(sorted + s0);
+        const u32 nk = nsyms - s0 < 8 ? nsyms - s0 : 8;
+        for (u32 k = 0; k < nk; k++, code++, left_len--) {
+            while (left_len == 0) {
+                len++;
+                left_len = cnt_get(count, len);
+                code = cnt_get(first, len);
+            }
+            u32 sw = (k >> 1) == 0 ? sv.x : (k >> 1) == 1 ? sv.y : (k >> 1) == 2 ? sv.z : sv.w;
+            u32 s = (k & 1) ? sw >> 16 : sw & 0xffff;
             u32 e = (s << 4) | len;
             if (len <= root) {
                 /* the replicas of one code are spread over the lanes of the group */
@@ -722,11 +733,16 @@ NOINL Hdr read_code_t(Hdr h, u32 num)
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (u32 i = 0; i < nnz; i++) {
-        u32 e = gld16(nz + i);
-        u32 l = e >> 12;
-        gst16(sorted + cnt_get(offs, l), e & 0xfff);
-        cnt_add(offs, l, 1);
+    for (u32 i0 = 0; i0 < nnz; i0 += 8) { /* eight entries to a load */
+        const u32x4 nv = gld128u(nz + i0);
+        const u32 nk = nnz - i0 < 8 ? nnz - i0 : 8;
+        for (u32 k = 0; k < nk; k++) {
+            u32 w = (k >> 1) == 0 ? nv.x : (k >> 1) == 1 ? nv.y : (k >> 1) == 2 ? nv.z : nv.w;
+            u32 e = (k & 1) ? w >> 16 : w & 0xffff;
+            u32 l = e >> 12;
+            gst16(sorted + cnt_get(offs, l), e & 0xfff);
+            cnt_add(offs, l, 1);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     build_table(h, count, rootcap_of(h));

@@ -595,6 +595,10 @@ DEV u32 metablock(Ctx &c, u32 sub)
     h.lds_used = h.lds_size = 0;
     h.rootcaps = c.rootcaps;
     h.kind = YS_KIND_OTHER;
+#ifdef YS_PROFILE
+    u64 hp_[6];
+    hp_[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     read_block_header(h, c.L);
     read_block_header(h, c.I);
     read_block_header(h, c.D);
@@ -624,6 +628,9 @@ DEV u32 metablock(Ctx &c, u32 sub)
     if (c.dist_codes > 1 && !h.r.rc)
         h = read_context_map(h, dist_map, c.D.num << 2, c.dist_codes);
 
+#ifdef YS_PROFILE
+    hp_[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     u32 *ldir = (u32 *)(c.ws + YS_WS_LDIR), *ddir = (u32 *)(c.ws + YS_WS_DDIR);
     u32 *itab = (u32 *)(c.ws + YS_WS_ITAB), *dtab = (u32 *)(c.ws + YS_WS_DTAB);
     h.kind = YS_KIND_LIT;
@@ -631,16 +638,25 @@ DEV u32 metablock(Ctx &c, u32 sub)
         h = read_code(h, 256);
         gst32(ldir + n, h.tab);
     }
+#ifdef YS_PROFILE
+    hp_[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     h.kind = YS_KIND_IAC;
     for (n = 0; n < c.I.num && !h.r.rc; n++) {
         h = read_code(h, 704);
         gst32(itab + n, h.tab);
     }
+#ifdef YS_PROFILE
+    hp_[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     h.kind = YS_KIND_DIST;
     for (n = 0; n < c.dist_codes && !h.r.rc; n++) {
         h = read_code(h, dists);
         gst32(ddir + n, h.tab);
     }
+#ifdef YS_PROFILE
+    hp_[4] = __builtin_amdgcn_s_memrealtime();
+#endif
     r = h.r;
     if (r.rc)
         return 1;
@@ -653,6 +669,15 @@ DEV u32 metablock(Ctx &c, u32 sub)
         for (n = sub; n < (c.D.num << 2); n += G)
             gst32(dtab + n, gld32(ddir + gld8(dist_map + n)));
     group_sync_mem();
+#ifdef YS_PROFILE
+    hp_[5] = __builtin_amdgcn_s_memrealtime();
+    if (FLAT && (threadIdx.x & 63) == 0 && c.cap >= 256) { /* block headers + maps, literal codes, insert-and-copy, distance, map resolution; counts */
+        u64 *hp = (u64 *)(c.out + c.cap - 256);
+        for (int i = 0; i < 5; i++)
+            hp[i] = hp_[i + 1] - hp_[i];
+        hp[5] = c.lit_codes | ((u64)c.I.num << 16) | ((u64)c.dist_codes << 32) | ((u64)c.L.num << 48);
+    }
+#endif
     const u16 *tI = tab_at(c, gld32(itab));
     u32 cur_mode = gld8(mode);
     const bool ctx = c.lit_codes > 1;

@@ -13,7 +13,7 @@ meta, distinct = H.packed_streams("cfg2_streams")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 order = np.random.RandomState(3).randint(0, len(distinct), size=n)
-b = DeviceBatch([distinct[j] for j in order], [65536 + 128] * n)
+b = DeviceBatch([distinct[j] for j in order], [65536 + 256] * n)
 b.decode(check=0, lanes=1); torch.cuda.synchronize()
 b.decode(check=0, lanes=1); torch.cuda.synchronize()
 r = b.records()
@@ -25,6 +25,11 @@ for i in range(0, n, S):
     e = int(offs[i + 1])
     rows.append(host[e - 128:e].view(np.uint64).astype(np.float64))
 A = np.stack(rows)
+H = np.stack([host[int(offs[i + 1]) - 256:int(offs[i + 1]) - 208].view(np.uint64).astype(np.float64) for i in range(0, n, S)])
+hm = np.median(H, axis=0)
+print("header of lane 0's stream, median (ms): block headers + context maps %.3f, literal codes %.3f, insert-and-copy codes %.3f, distance codes %.3f, map resolution %.3f" % tuple(hm[:5] / 1e5))
+cnt = H[:, 5].astype(np.uint64)
+print("mean number of literal codes %.1f, insert-and-copy %.1f, distance %.1f, literal block types %.1f" % ((cnt & 0xffff).mean(), ((cnt >> 16) & 0xffff).mean(), ((cnt >> 32) & 0xffff).mean(), (cnt >> 48).mean()))
 m = A.mean(0)
 # prof[12] = trips of the wavefront, [13] = header and tables, [14] = the loop (both in 10 ns units)
 print("trips per wavefront: mean %.0f max %.0f" % (m[12], A[:, 12].max()))
