@@ -220,6 +220,9 @@ struct Hdr {
     u32 rootcaps; /* root table width by kind: other | literal << 8 | insert-and-copy << 16 | distance << 24
                      (global tables: exactly that wide; LDS mode: at most that wide) */
     u32 kind;     /* YS_KIND_* of the code read next */
+#ifdef YS_PROFILE
+    u64 tp0, tp1, tp2, tp3; /* read_code: code length code, lengths, sort, table (10 ns units) */
+#endif
 };
 
 /* A wavefront that decodes ONE stream holds the same value of all of this in every lane, but a
@@ -527,6 +530,9 @@ NOINL Hdr read_code_t(Hdr h, u32 num)
     Rd &r = h.r;
     u16 *sorted = (u16 *)(h.ws + YS_WS_SORT);
     h.tab = YS_WS_ARENA;
+#ifdef YS_PROFILE
+    u64 tq0 = __builtin_amdgcn_s_memrealtime();
+#endif
     u32 hskip = take(r, 2);
     Cnt16 count;
     cnt_clear(count);
@@ -646,6 +652,9 @@ NOINL Hdr read_code_t(Hdr h, u32 num)
         }
     }
 
+#ifdef YS_PROFILE
+    u64 tq1 = __builtin_amdgcn_s_memrealtime();
+#endif
     /* ---- the code lengths themselves, yeast.c:464-518 ---- */
     if (!h.lds && h.arena_used + 704 * 2 + 16 + YS_TAB_ENTRIES * 2 > h.arena_size) {
         rd_fail(r, YS_WORKSPACE);
@@ -722,6 +731,9 @@ NOINL Hdr read_code_t(Hdr h, u32 num)
         build_table_lds(h, count, nz, nnz, rootcap_of(h));
         return h;
     }
+#ifdef YS_PROFILE
+    u64 tq2 = __builtin_amdgcn_s_memrealtime();
+#endif
     /* counting sort into canonical order (construct() yeast.c:266-277) */
     Cnt16 offs;
     cnt_clear(offs);
@@ -745,7 +757,13 @@ NOINL Hdr read_code_t(Hdr h, u32 num)
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef YS_PROFILE
+    u64 tq3 = __builtin_amdgcn_s_memrealtime();
+#endif
     build_table(h, count, rootcap_of(h));
+#ifdef YS_PROFILE
+    h.tp0 += tq1 - tq0; h.tp1 += tq2 - tq1; h.tp2 += tq3 - tq2; h.tp3 += __builtin_amdgcn_s_memrealtime() - tq3;
+#endif
     return h;
 }
 

@@ -598,6 +598,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
 #ifdef YS_PROFILE
     u64 hp_[6];
     hp_[0] = __builtin_amdgcn_s_memrealtime();
+    h.tp0 = h.tp1 = h.tp2 = h.tp3 = 0;
 #endif
     read_block_header(h, c.L);
     read_block_header(h, c.I);
@@ -676,6 +677,7 @@ DEV u32 metablock(Ctx &c, u32 sub)
         for (int i = 0; i < 5; i++)
             hp[i] = hp_[i + 1] - hp_[i];
         hp[5] = c.lit_codes | ((u64)c.I.num << 16) | ((u64)c.dist_codes << 32) | ((u64)c.L.num << 48);
+        hp[6] = h.tp0; hp[7] = h.tp1; hp[8] = h.tp2; hp[9] = h.tp3;
     }
 #endif
     const u16 *tI = tab_at(c, gld32(itab));

@@ -25,9 +25,10 @@ for i in range(0, n, S):
     e = int(offs[i + 1])
     rows.append(host[e - 128:e].view(np.uint64).astype(np.float64))
 A = np.stack(rows)
-H = np.stack([host[int(offs[i + 1]) - 256:int(offs[i + 1]) - 208].view(np.uint64).astype(np.float64) for i in range(0, n, S)])
+H = np.stack([host[int(offs[i + 1]) - 256:int(offs[i + 1]) - 176].view(np.uint64).astype(np.float64) for i in range(0, n, S)])
 hm = np.median(H, axis=0)
 print("header of lane 0's stream, median (ms): block headers + context maps %.3f, literal codes %.3f, insert-and-copy codes %.3f, distance codes %.3f, map resolution %.3f" % tuple(hm[:5] / 1e5))
+print("complex prefix codes of a stream, median (ms): code length code %.3f, code lengths %.3f, counting sort %.3f, table %.3f" % tuple(hm[6:10] / 1e5))
 cnt = H[:, 5].astype(np.uint64)
 print("mean number of literal codes %.1f, insert-and-copy %.1f, distance %.1f, literal block types %.1f" % ((cnt & 0xffff).mean(), ((cnt >> 16) & 0xffff).mean(), ((cnt >> 32) & 0xffff).mean(), (cnt >> 48).mean()))
 m = A.mean(0)
