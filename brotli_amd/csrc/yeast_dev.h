@@ -48,6 +48,11 @@ DEV void gst8(void *p, u32 v) { *(GAS u8 *)p = (u8)v; }
 DEV void gst16(void *p, u32 v) { *(GAS u16 *)p = (u16)v; }
 DEV void gst32(void *p, u32 v) { *(GAS u32 *)p = v; }
 DEV void gst64(void *p, u64 v) { *(GAS u64 *)p = v; }
+DEV void gst32u(void *p, u32 v) /* unaligned */
+{
+    typedef u32 __attribute__((aligned(1))) u32u;
+    *(GAS u32u *)p = v;
+}
 DEV void gst64u(void *p, u64 v)
 {
     typedef u64 __attribute__((aligned(1))) u64u;

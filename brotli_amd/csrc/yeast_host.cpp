@@ -34,7 +34,7 @@ size_t ys_static_bytes(void);
 int ys_launch_decode_static(const ys_params *p, int device, void *stream);
 int ysl_upload_constants(const u8 *lut768);
 int ysl_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base, u8 *xdict, void *stream);
-int ysl_launch(const ys_params *p, int half, unsigned streams, void *stream);
+int ysl_launch(const ys_params *p, int half, int merge, unsigned streams, void *stream);
 int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *order, void *stream);
 int ysw_upload_constants(const u8 *lut768);
 unsigned ysw_shared_bytes(void);
@@ -307,7 +307,7 @@ static const char *const KNOB_NAMES[] = {"YEAST_LANES", "YEAST_WAVES_PER_CU", "Y
                                          "YEAST_ROOT_IAC", "YEAST_ROOT_DIST", "YEAST_HALF", "YEAST_BLOCKS_PER_CU",
                                          "YEAST_WS_KB", "YEAST_LEAN_ROOT_LIT", "YEAST_LEAN_ROOT_IAC",
                                          "YEAST_LEAN_ROOT_DIST", "YEAST_SORT", "YEAST_DEBUG", "YEAST_HOST_THREADS",
-                                         "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB"};
+                                         "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB", "YEAST_MERGE"};
 enum { KNOBS = sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]) };
 static int g_knob_val[KNOBS];
 static bool g_knob_set[KNOBS];
@@ -461,7 +461,10 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
             p.order = order;
         }
         p.debug = (u32)env_int("YEAST_DEBUG", 0);
-        e = ysl_launch(&p, half, groups, st);
+        /* batches that fill the GPU: the loop with one store per run of literals (4 % faster at 65,536 streams and more,
+           6 % slower at 32,768 and fewer: tools/ab.sh with YEAST_MERGE) */
+        const int merge = env_int("YEAST_MERGE", n > (size_t)d.cus * 192 ? 1 : 0);
+        e = ysl_launch(&p, half, merge, groups, st);
         p.order = nullptr;
         p.debug = 0;
     }

@@ -36,12 +36,13 @@ def plan_output(capacities: Sequence[int], align: int = 64):
 class DeviceBatch:
     """A batch resident in HBM: packed input, offsets, output arena, records."""
 
-    def __init__(self, streams: Sequence[bytes], capacities: Sequence[int], device="cuda"):
+    def __init__(self, streams: Sequence[bytes], capacities: Sequence[int], device="cuda", align: int = 64):
+        """align: alignment of the output regions (1: back to back, every region exactly its capacity)"""
         import torch
         self.torch = torch
         self.n = len(streams)
         buf, soff = pack_streams(streams)
-        doff = plan_output(capacities)
+        doff = plan_output(capacities, align)
         self.src = torch.from_numpy(buf).to(device)
         self.src_off = torch.from_numpy(soff.view(np.int64)).to(device)
         self.dst_off = torch.from_numpy(doff.view(np.int64)).to(device)

@@ -190,6 +190,44 @@ def test_randomly_assembled_streams(lanes, monkeypatch):
         assert r[1] == out, i
 
 
+def test_batch_kernel_with_literals_gathered_per_run(monkeypatch):
+    # the form of the batch kernel that large batches get (one store per run of literals, YEAST_MERGE): forced here
+    # on small batches -- crafted streams, the corpus, random streams whole and damaged, outputs that end exactly at
+    # the end of their region (the 4-byte store must not reach into the next stream's region)
+    import random_plans as R
+    monkeypatch.setenv("YEAST_FORCE_LANES", "1")
+    monkeypatch.setenv("YEAST_MERGE", "1")
+    cr = H.load_json("crafted.json")
+    cases = [bytes.fromhex(v["hex"]) for v in cr.values()]
+    cases += [comp for _, comp, _ in H.testdata_pairs()]
+    ss = R.streams(300, 99)
+    cases += [s for s, _ in ss]
+    rnd = random.Random(3)
+    for s, _ in ss[:200]:
+        b = bytearray(s)
+        if rnd.random() < 0.3:
+            b = b[:rnd.randrange(1, len(b) + 1)]
+        for _ in range(rnd.randrange(1, 4)):
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        cases.append(bytes(b))
+    want = [H.oracle_yeast(s) for s in cases]
+    for i, (w, r) in enumerate(zip(want, ba.yeast_batch(cases, ba.CHECK_XXH64))):
+        assert (r[0], r[2], r[3]) == w[:3], i
+        assert r[1] == w[3], i
+    # device call with regions exactly as long as the outputs, back to back: a byte written past a region shows up
+    # as a wrong check of the next stream
+    from brotli_amd.device import DeviceBatch
+    good = [(s, w) for s, w in zip(cases, want) if w[0] == 0 and w[1] > 0][:400]
+    b = DeviceBatch([s for s, _ in good], [w[1] for _, w in good], align=1)
+    assert (np.diff(b.host_dst_off.astype(np.int64)) == np.array([w[1] for _, w in good])).all()
+    b.decode(check=ba.CHECK_NONE, lanes=1)
+    rec = b.records()
+    for i, (s, w) in enumerate(good):
+        assert (rec[i]["rc"], rec[i]["got"], rec[i]["used"]) == w[:3], i
+    whole = bytes(b.dst[:int(b.host_dst_off[-1])].cpu().numpy())
+    assert whole == b"".join(w[3] for _, w in good)
+
+
 def test_host_batch_in_passes_under_a_memory_budget(monkeypatch):
     # a host batch larger than the share of device memory it may take goes in several passes with the same
     # results; a stream that does not fit the budget by itself is out of memory (code 1) and the others decode
