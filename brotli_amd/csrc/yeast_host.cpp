@@ -461,8 +461,8 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
             p.order = order;
         }
         p.debug = (u32)env_int("YEAST_DEBUG", 0);
-        /* batches that fill the GPU: the loop with one store per run of literals (4 % faster at 65,536 streams and more,
-           6 % slower at 32,768 and fewer: tools/ab.sh with YEAST_MERGE) */
+        /* batches that fill the GPU: the loop with one store per command (a piece and the literals behind it: 6 % faster
+           at 65,536 streams and more, 8 % slower at 32,768 and fewer: tools/ab.sh with YEAST_MERGE) */
         const int merge = env_int("YEAST_MERGE", n > (size_t)d.cus * 192 ? 1 : 0);
         e = ysl_launch(&p, half, merge, groups, st);
         p.order = nullptr;

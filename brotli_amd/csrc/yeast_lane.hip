@@ -15,9 +15,9 @@
 #ifndef YS_MAX_OCC
 #define YS_MAX_OCC 4 /* blocks per CU the register budget is cut for (experiments: 2 leaves S = 16 unspilled) */
 #endif
-/* MERGE: the loop that gathers the literals of a run into one store (yeast_trip.h): for batches that keep every SIMD
-   busy with two wavefronts */
-template <int S, bool MERGE = false>
+/* UNIT: the loop that stores a copy's last piece and the literals behind it as one unit (yeast_trip.h): for batches that
+   keep every SIMD busy with two wavefronts */
+template <int S, int UNIT = 0>
 __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) void k_decode_lean(ys_params p)
 {
     __shared__ TripShared tsh;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
                 job = p.retry_list[job];
             else if (p.order)
                 job = p.order[job];
-            decode_stream<1, false, S | (MERGE ? 0x100 : 0)>(p, job, ws, shp, 0, &wlds[lane >> 6], tsp, wbase);
+            decode_stream<1, false, S | (UNIT << 8)>(p, job, ws, shp, 0, &wlds[lane >> 6], tsp, wbase);
         }
     }
 }
@@ -161,12 +161,12 @@ extern "C" int ysl_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base
     return (int)hipGetLastError();
 }
 
-template <int S, bool MERGE = false>
+template <int S, int UNIT = 0>
 static int launch_lean_t(const ys_params &p, u32 streams, hipStream_t st)
 {
     u32 per_block = 4 * S;
     u32 blocks = (streams + per_block - 1) / per_block;
-    hipLaunchKernelGGL((k_decode_lean<S, MERGE>), dim3(blocks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_decode_lean<S, UNIT>), dim3(blocks), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
 
@@ -174,7 +174,7 @@ static int launch_lean_t(const ys_params &p, u32 streams, hipStream_t st)
 extern "C" int ysl_launch(const ys_params *p, int half, int merge, unsigned streams, void *stream)
 {
     if (half == 1 && merge)
-        return launch_lean_t<32, true>(*p, streams, (hipStream_t)stream);
+        return launch_lean_t<32, 1>(*p, streams, (hipStream_t)stream);
     if (half == 2) /* quarter-filled wavefronts (a test and measurement shape: the kernel needs ~196 registers with its
                       out-of-line header code, so two wavefronts per SIMD are resident whatever the shape) */
         return launch_lean_t<16>(*p, streams, (hipStream_t)stream);

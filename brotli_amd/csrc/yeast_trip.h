@@ -42,6 +42,7 @@ struct TripLds {
     u32 ent[64];
     u32x4 top[64];
     u32x4 piece[64];
+    u32x4 unit[64]; /* UNIT form of the loop: the output unit being put together (a piece and the literals behind it) */
 };
 
 /* LDS image shared by the wavefronts of a block */
@@ -137,15 +138,17 @@ DEV void lds_load16_nt(const u8 *src, u32 lds) /* read once: not worth a place i
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(src), "s"(lds) : "memory");
 }
 
-/* SF: streams per wavefront, and in bit 8 whether literals are gathered into one store per run (MERGE below) */
+/* SF: streams per wavefront, and in bit 8 the form of the loop's stores (UNIT below) */
 template <int SF>
 NOINL TripOut run_trip_fn(TripIn a)
 {
     constexpr int S = SF & 0xff;
-    /* Literals wait in a register for the end of their run (or for four of them) and go out in one 4-byte store.
-       Fewer requests to memory: 4 % faster when both wavefronts of every SIMD are busy (65,536 streams and more),
-       more instructions per trip: 6 % slower below that -- so the kernel exists in both forms (yeast_lane.hip). */
-    constexpr bool MERGE = (SF & 0x100) != 0;
+    /* UNIT: one 16-byte store per command -- the last piece of a copy is not stored when it lands but kept in LDS, the
+       literals that follow are put behind it, and the unit goes out when it is full or when the next copy is about to
+       read from the output.  Fewer requests to memory: 6 % faster when both wavefronts of every SIMD are busy (65,536
+       streams and more); more LDS round trips per trip: 8 % slower below that -- so the kernel exists in both forms
+       (yeast_lane.hip). */
+    constexpr bool UNIT = (SF & 0x100) != 0;
     LAS TripLds<S> *wl = (LAS TripLds<S> *)a.wl;
     LAS const TripShared *ts = a.ts;
     const u32 slot = threadIdx.x & 63;
@@ -233,7 +236,7 @@ NOINL TripOut run_trip_fn(TripIn a)
     u32 dsym = 0, dxv = 0;
     const u8 *csrc = a.outp; /* copy in progress: source of the next piece, bytes left, period limit */
     u32 crem = 0, cD = 0;
-    u32 lb = 0, ln = 0; /* MERGE: literals not stored yet (up to three), lowest byte first */
+    u32 wn = 0;         /* UNIT: bytes in the unit that is being put together */
     u32 pn = 0; /* bytes of the piece requested on the last trip (it lands in wl->piece and goes to op - pn) */
 
     /* ---- the lookup in flight (its entry lands in wl->ent) ---- */
@@ -497,36 +500,47 @@ NOINL TripOut run_trip_fn(TripIn a)
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
         pwait3 += tb_ - ta_;
 #endif
-        if (pn) {
-            const LAS u8 *pb = (const LAS u8 *)&wl->piece[slot];
-            u32 b1 = pb[pn - 1], b2 = pb[pn >= 2 ? pn - 2 : 0];
-            gst128u(op - pn, wl->piece[slot]);
-            p2 = pn >= 2 ? b2 : p1;
-            p1 = b1;
-        }
-        pn = 0;
-        if constexpr (MERGE) {
-            /* a unit of four bytes: what lies behind the literals is overwritten by what follows, except at the very
-               end of the output region */
-            lb |= dL ? sym << (8 * ln) : 0u;
-            ln += dL;
+        if constexpr (UNIT) {
+            const bool reads = start | (crem != 0); /* a piece is loaded on this trip: the output must be in memory */
+            const bool dead = ends | (rc != 0) | (st == YT_END);
+            LAS u8 *ub = (LAS u8 *)&wl->unit[slot];
+            if (pn) { /* the piece that landed opens a unit (the one before went out when this piece was asked for) */
+                const LAS u8 *pb = (const LAS u8 *)&wl->piece[slot];
+                u32 b1 = pb[pn - 1], b2 = pb[pn >= 2 ? pn - 2 : 0];
+                wl->unit[slot] = wl->piece[slot];
+                p2 = pn >= 2 ? b2 : p1;
+                p1 = b1;
+            }
+            wn = pn ? pn : wn;
+            pn = 0;
+            if (dL)
+                ub[wn] = (u8)sym;
+            wn += dL;
             op += dL;
-            /* (no short-circuit operators: they become branches) */
-            const bool fl = (ln != 0) & ((ln == 4) | (dL & !lits) | (st == YT_END) | (rc != 0) | eof);
-            const u32 gotl = (u32)(uintptr_t)op - out_lo;
-            const bool lnear = fl & (gotl - ln + 4 > cap);
-            if (fl & !lnear)
-                gst32u(op - ln, lb);
-            if (__any(lnear)) {
-                if (lnear) {
+            const bool fl = (wn != 0) & ((wn == 16) | reads | dead);
+            const u32 gotw = (u32)(uintptr_t)op - out_lo;
+            const bool wnear = fl & (gotw - wn + 16 > cap); /* the last 16 bytes of the region: nothing is written beyond it */
+            if (fl & !wnear)
+                gst128u(op - wn, wl->unit[slot]);
+            if (__any(wnear)) {
+                if (wnear) {
 #pragma clang loop unroll(disable) vectorize(disable)
-                    for (u32 j = 0; j < ln; j++)
-                        gst8(op - ln + j, (lb >> (8 * j)) & 255);
+                    for (u32 j = 0; j < wn; j++)
+                        gst8(op - wn + j, ub[j]);
                 }
             }
-            lb = fl ? 0 : lb;
-            ln = fl ? 0 : ln;
+            wn = fl ? 0 : wn;
         } else {
+            /* the piece goes out when it has landed (a whole unit; the excess is overwritten by what follows), then this
+               trip's literal */
+            if (pn) {
+                const LAS u8 *pb = (const LAS u8 *)&wl->piece[slot];
+                u32 b1 = pb[pn - 1], b2 = pb[pn >= 2 ? pn - 2 : 0];
+                gst128u(op - pn, wl->piece[slot]);
+                p2 = pn >= 2 ? b2 : p1;
+                p1 = b1;
+            }
+            pn = 0;
             if (dL)
                 gst8(op, sym);
             op += dL;
@@ -673,10 +687,11 @@ NOINL TripOut run_trip_fn(TripIn a)
     /* meta-block end (or failure): the piece set up last was valid */
     if (pn)
         gst128u(op - pn, wl->piece[slot]);
-    if constexpr (MERGE) {
+    if constexpr (UNIT) {
+        const LAS u8 *ub = (const LAS u8 *)&wl->unit[slot];
 #pragma clang loop unroll(disable) vectorize(disable)
-        for (u32 j = 0; j < ln; j++)
-            gst8(op - ln + j, (lb >> (8 * j)) & 255);
+        for (u32 j = 0; j < wn; j++)
+            gst8(op - wn + j, ub[j]);
     }
     TripOut o;
     o.outp = op;

@@ -190,10 +190,11 @@ def test_randomly_assembled_streams(lanes, monkeypatch):
         assert r[1] == out, i
 
 
-def test_batch_kernel_with_literals_gathered_per_run(monkeypatch):
-    # the form of the batch kernel that large batches get (one store per run of literals, YEAST_MERGE): forced here
+def test_batch_kernel_with_one_store_per_command(monkeypatch):
+    # the form of the batch kernel that large batches get (a copy's last piece and the literals behind it stored as one
+    # unit, YEAST_MERGE): forced here
     # on small batches -- crafted streams, the corpus, random streams whole and damaged, outputs that end exactly at
-    # the end of their region (the 4-byte store must not reach into the next stream's region)
+    # the end of their region (the 16-byte store must not reach into the next stream's region)
     import random_plans as R
     monkeypatch.setenv("YEAST_FORCE_LANES", "1")
     monkeypatch.setenv("YEAST_MERGE", "1")
