@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak: many randomly assembled streams (tests/random_plans.py, several seeds) through the batch kernel and
-the wavefront-per-stream kernel against the CPU restatement.  usage: tools/soak_random.py [seeds] [streams per seed]"""
+(both forms) and the wavefront-per-stream kernel against the CPU restatement.
+usage: tools/soak_random.py [seeds] [streams per seed] [damaged: 0|1] [first seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,10 +11,11 @@ import brotli_amd as ba
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 bad = 0
-for seed in range(100, 100 + seeds):
+first = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+for seed in range(first, first + seeds):
     t0 = time.time()
     ss = R.streams(per, seed)
-    if len(sys.argv) > 3:  # damaged copies too: bit flips and cuts anywhere (same rc, got, used and partial output wanted)
+    if len(sys.argv) > 3 and sys.argv[3] != "0":  # damaged copies too: bit flips and cuts anywhere (same rc, got, used and partial output wanted)
         import random
         rnd = random.Random(seed)
         extra = []
@@ -26,13 +28,14 @@ for seed in range(100, 100 + seeds):
             extra.append((bytes(b), None))
         ss = ss + extra
     want = [H.oracle_yeast(s) for s, _ in ss]
-    for lanes in (1, 65):
+    for lanes, merge in ((1, 0), (1, 1), (65, 0)):
         os.environ["YEAST_FORCE_LANES"] = str(lanes)
+        os.environ["YEAST_MERGE"] = str(merge)
         res = ba.yeast_batch([s for s, _ in ss], ba.CHECK_NONE)
         for i, (w, r) in enumerate(zip(want, res)):
             if (r[0], r[2], r[3], r[1]) != (w[0], w[1], w[2], w[3]):
                 bad += 1
-                print("MISMATCH seed %d stream %d lanes %d: gpu %s oracle %s" % (seed, i, lanes, (r[0], r[2], r[3]), w[:3]), flush=True)
+                print("MISMATCH seed %d stream %d lanes %d merge %d: gpu %s oracle %s" % (seed, i, lanes, merge, (r[0], r[2], r[3]), w[:3]), flush=True)
     print("seed %d: %d streams, %.1f s" % (seed, per, time.time() - t0), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
