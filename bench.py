@@ -172,6 +172,7 @@ def main():
             raise SystemExit("bench: fewer streams than ranks")
     else:
         order = build_order(args.streams, len(distinct), 0x5EED + rank, args.order)
+        sizes = [len(order) * 32] * world  # every rank decodes as many streams: no exchange of counts in the step
     n = len(order)
     streams = [distinct[j] for j in order]
     batch = DeviceBatch(streams, [65536] * n, device=dev)
