@@ -461,9 +461,11 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
             p.order = order;
         }
         p.debug = (u32)env_int("YEAST_DEBUG", 0);
-        /* batches that fill the GPU: the loop with one store per command (a piece and the literals behind it: 6 % faster
-           at 65,536 streams and more, 8 % slower at 32,768 and fewer: tools/ab.sh with YEAST_MERGE) */
-        const int merge = env_int("YEAST_MERGE", n > (size_t)d.cus * 192 ? 1 : 0);
+        /* batches that fill the GPU: the loop that gathers its stores (yeast_trip.h; YEAST_MERGE 2: every output byte
+           through a ring in LDS and out in complete 16-byte chunks, 47.6 ms against 57.4 at 65,536 streams; 1: one store
+           per command, 52.6 ms; 0: the plain loop, faster at 32,768 streams and fewer, where a wavefront has its SIMD to
+           itself and every LDS round trip shows) */
+        const int merge = env_int("YEAST_MERGE", n > (size_t)d.cus * 192 ? 2 : 0);
         e = ysl_launch(&p, half, merge, groups, st);
         p.order = nullptr;
         p.debug = 0;

@@ -173,6 +173,8 @@ static int launch_lean_t(const ys_params &p, u32 streams, hipStream_t st)
 /* streams = resident streams (each owns one workspace slot); half != 0: half-filled wavefronts */
 extern "C" int ysl_launch(const ys_params *p, int half, int merge, unsigned streams, void *stream)
 {
+    if (half == 1 && merge == 2)
+        return launch_lean_t<32, 2>(*p, streams, (hipStream_t)stream);
     if (half == 1 && merge)
         return launch_lean_t<32, 1>(*p, streams, (hipStream_t)stream);
     if (half == 2) /* quarter-filled wavefronts (a test and measurement shape: the kernel needs ~196 registers with its

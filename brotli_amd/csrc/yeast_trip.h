@@ -32,6 +32,12 @@
 #ifndef YEAST_TRIP_H
 #define YEAST_TRIP_H
 
+/* RING form: bytes of LDS per stream (the ring proper is [0, 64) behind 32 bytes of slack; what is written at
+   [0, 16) is written at [64, 80) too and the other way round, so sixteen bytes can be read or written at any offset
+   below 64 in one piece; 37 words: the streams' rings start in different banks) */
+#define YT_RING_STRIDE 148
+typedef u32x4 __attribute__((aligned(1))) u32x4u;
+
 /* per-wavefront LDS: [index][stream], so the streams of a wavefront use different banks */
 template <int S>
 struct TripLds {
@@ -42,7 +48,9 @@ struct TripLds {
     u32 ent[64];
     u32x4 top[64];
     u32x4 piece[64];
-    u32x4 unit[64]; /* UNIT form of the loop: the output unit being put together (a piece and the literals behind it) */
+    u32x4 unit[64]; /* UNIT form of the loop: the output unit being put together (a piece and the literals behind it);
+                       RING form: where a piece taken from the ring waits for the next trip */
+    u8 ring[32 * YT_RING_STRIDE + 16]; /* RING form: the last 64 bytes of each stream's output (see run_trip_fn) */
 };
 
 /* LDS image shared by the wavefronts of a block */
@@ -149,6 +157,14 @@ NOINL TripOut run_trip_fn(TripIn a)
        streams and more); more LDS round trips per trip: 8 % slower below that -- so the kernel exists in both forms
        (yeast_lane.hip). */
     constexpr bool UNIT = (SF & 0x100) != 0;
+    /* RING: chunk write-behind.  Every output byte goes through a 64-byte ring per stream in LDS; a trip stores at most
+       one chunk of sixteen bytes and only a complete one, on the 16-byte grid that starts where this call's output
+       starts -- so each byte is written to memory once.  A copy from less than 48 bytes back takes its piece from the
+       ring (the bytes may not be in memory yet); one from further back reads memory, where everything but the last
+       fifteen bytes is.  What is left at the end of the loop goes out byte by byte, so nothing is written beyond the
+       output region and the loop needs no special case for the region's last bytes. */
+    constexpr bool RING = (SF & 0x200) != 0;
+    static_assert(!RING || S == 32, "the ring is laid out for 32 streams per wavefront");
     LAS TripLds<S> *wl = (LAS TripLds<S> *)a.wl;
     LAS const TripShared *ts = a.ts;
     const u32 slot = threadIdx.x & 63;
@@ -236,7 +252,19 @@ NOINL TripOut run_trip_fn(TripIn a)
     u32 dsym = 0, dxv = 0;
     const u8 *csrc = a.outp; /* copy in progress: source of the next piece, bytes left, period limit */
     u32 crem = 0, cD = 0;
-    u32 wn = 0;         /* UNIT: bytes in the unit that is being put together */
+    u32 wn = 0;         /* UNIT: bytes in the unit that is being put together; RING: bytes in the ring that are not in memory yet */
+    bool pl = false;    /* RING: the piece asked for on the last trip came from the ring and waits in wl->unit */
+    const u32 base_lo = (u32)(uintptr_t)a.outp; /* RING: where this call's output starts: byte k of it lives at ring offset k & 63 */
+    LAS u8 *const rb = (LAS u8 *)wl->ring + (slot & 31) * YT_RING_STRIDE + 32;
+    if constexpr (RING) { /* the output of earlier meta-blocks that a copy may reach through the ring */
+        u64 got0 = (u64)(a.outp - a.out);
+        u32 k = got0 < 48 ? (u32)got0 : 48u;
+        for (u32 j = 1; j <= k; j++) {
+            u32 o = (0u - j) & 63, v = gld8(a.outp - j);
+            rb[o] = (u8)v;
+            rb[o < 32 ? o + 64 : o - 64] = (u8)v;
+        }
+    }
     u32 pn = 0; /* bytes of the piece requested on the last trip (it lands in wl->piece and goes to op - pn) */
 
     /* ---- the lookup in flight (its entry lands in wl->ent) ---- */
@@ -500,7 +528,34 @@ NOINL TripOut run_trip_fn(TripIn a)
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
         pwait3 += tb_ - ta_;
 #endif
-        if constexpr (UNIT) {
+        if constexpr (RING) {
+            const u32 ac = (u32)(uintptr_t)op - base_lo; /* bytes produced by this call, the piece that landed included */
+            if (pn) {
+                const LAS u8 *pb = pl ? (const LAS u8 *)&wl->unit[slot] : (const LAS u8 *)&wl->piece[slot];
+                u32 b1 = pb[pn - 1], b2 = pb[pn >= 2 ? pn - 2 : 0];
+                const u32x4 pv = *(const LAS u32x4 *)pb;
+                const u32 o = (ac - pn) & 63;
+                *(LAS u32x4u *)(rb + o) = pv; /* sixteen bytes whatever pn: the excess lies where the next bytes go */
+                *(LAS u32x4u *)(rb + (o < 32 ? o + 64 : o - 64)) = pv;
+                p2 = pn >= 2 ? b2 : p1;
+                p1 = b1;
+            }
+            wn += pn;
+            pn = 0;
+            if (dL) {
+                const u32 o = ac & 63;
+                rb[o] = (u8)sym;
+                rb[o < 32 ? o + 64 : o - 64] = (u8)sym;
+            }
+            wn += dL;
+            op += dL;
+            const bool fl = wn >= 16; /* at most 15 + 16 before: one chunk a trip keeps up */
+            if (fl) {
+                const u32 co = ((u32)(uintptr_t)op - base_lo - wn) & 63; /* a multiple of 16 */
+                gst128u(op - wn, *(const LAS u32x4u *)(rb + co));
+            }
+            wn -= fl ? 16u : 0u;
+        } else if constexpr (UNIT) {
             const bool reads = start | (crem != 0); /* a piece is loaded on this trip: the output must be in memory */
             const bool dead = ends | (rc != 0) | (st == YT_END);
             LAS u8 *ub = (LAS u8 *)&wl->unit[slot];
@@ -641,7 +696,23 @@ NOINL TripOut run_trip_fn(TripIn a)
         }
         TMARK(6);
         /* the next piece of the copy in progress: requested now, stored on the next trip */
-        {
+        if constexpr (RING) {
+            const bool piece = crem != 0;
+            const bool nearc = piece && (u64)(op - csrc) < 48; /* a dictionary word is never that close */
+            m = piece ? m : 0;
+            lds_load16_nt(piece && !nearc ? csrc : wsb, lds_piece);
+            if (__any(nearc)) {
+                if (nearc)
+                    wl->unit[slot] = *(const LAS u32x4u *)(rb + (((u32)(uintptr_t)csrc - base_lo) & 63));
+            }
+            pl = nearc;
+            pn = m;
+            op += m;
+            crem -= m;
+            const bool whole = m == cD; /* a whole period is written: twice as far back is the same data */
+            cD = whole ? cD * 2 : cD;
+            csrc += whole ? 0 : m;
+        } else {
             const bool piece = crem != 0;
             const bool tail = piece && got + 16 > cap; /* the last bytes of the output region: nothing is written beyond it */
             if (__any(tail)) {
@@ -684,6 +755,21 @@ NOINL TripOut run_trip_fn(TripIn a)
         prof[14] = __builtin_amdgcn_s_memrealtime() - t_loop;
     }
 #endif
+    if constexpr (RING) { /* the piece set up last, then what the ring still holds, byte by byte */
+        if (pn) {
+            const u32x4 pv = pl ? wl->unit[slot] : wl->piece[slot];
+            const u32 o = ((u32)(uintptr_t)op - base_lo - pn) & 63;
+            *(LAS u32x4u *)(rb + o) = pv;
+            *(LAS u32x4u *)(rb + (o < 32 ? o + 64 : o - 64)) = pv;
+            wn += pn;
+            pn = 0;
+        }
+        const u32 co = (u32)(uintptr_t)op - base_lo - wn;
+#pragma clang loop unroll(disable) vectorize(disable)
+        for (u32 j = 0; j < wn; j++)
+            gst8(op - wn + j, rb[(co + j) & 63]);
+        wn = 0;
+    }
     /* meta-block end (or failure): the piece set up last was valid */
     if (pn)
         gst128u(op - pn, wl->piece[slot]);

@@ -190,14 +190,16 @@ def test_randomly_assembled_streams(lanes, monkeypatch):
         assert r[1] == out, i
 
 
-def test_batch_kernel_with_one_store_per_command(monkeypatch):
-    # the form of the batch kernel that large batches get (a copy's last piece and the literals behind it stored as one
-    # unit, YEAST_MERGE): forced here
+@pytest.mark.parametrize("merge", [1, 2])
+def test_batch_kernel_with_one_store_per_command(monkeypatch, merge):
+    # the forms of the batch kernel that gather the stores of the output (YEAST_MERGE 1: a copy's last piece and the
+    # literals behind it stored as one unit, the form large batches get; 2: every byte through a ring in LDS and out in
+    # complete 16-byte chunks, near copies served from the ring): forced here
     # on small batches -- crafted streams, the corpus, random streams whole and damaged, outputs that end exactly at
     # the end of their region (the 16-byte store must not reach into the next stream's region)
     import random_plans as R
     monkeypatch.setenv("YEAST_FORCE_LANES", "1")
-    monkeypatch.setenv("YEAST_MERGE", "1")
+    monkeypatch.setenv("YEAST_MERGE", str(merge))
     cr = H.load_json("crafted.json")
     cases = [bytes.fromhex(v["hex"]) for v in cr.values()]
     cases += [comp for _, comp, _ in H.testdata_pairs()]

@@ -29,7 +29,7 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
         if vals:
             tot[name] = sum(vals) / len(vals) * 1024.0
 if len(tot) == 2 and len(sys.argv) > 2:
-    out = {"streams": int(sys.argv[2]), "kernel": "k_decode_lean<32, 1>", "fetch_bytes": tot["FETCH_SIZE"],
+    out = {"streams": int(sys.argv[2]), "kernel": "k_decode_lean<32, 2>", "fetch_bytes": tot["FETCH_SIZE"],
            "fetch_bytes_gfx950_corrected": 2 * tot["FETCH_SIZE"],
            "write_bytes": tot["WRITE_SIZE"], "bytes_per_launch": 2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"],
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB x 1024, FETCH_SIZE x 2 "

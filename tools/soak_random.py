@@ -28,7 +28,7 @@ for seed in range(first, first + seeds):
             extra.append((bytes(b), None))
         ss = ss + extra
     want = [H.oracle_yeast(s) for s, _ in ss]
-    for lanes, merge in ((1, 0), (1, 1), (65, 0)):
+    for lanes, merge in ((1, 0), (1, 1), (1, 2), (65, 0)):
         os.environ["YEAST_FORCE_LANES"] = str(lanes)
         os.environ["YEAST_MERGE"] = str(merge)
         res = ba.yeast_batch([s for s, _ in ss], ba.CHECK_NONE)
