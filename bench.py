@@ -118,7 +118,7 @@ def kernel_label(n, lanes):
         return "k_decode_wave"
     if lanes == 1:
         half = int(os.environ.get("YEAST_HALF", "1"))
-        unit = int(os.environ.get("YEAST_MERGE", "2" if n > 49152 else "0"))  # the loop that gathers its stores: large batches
+        unit = int(os.environ.get("YEAST_MERGE", "2" if n >= 40960 else "0"))  # the loop that gathers its stores: large batches
         if half == 1 and unit:
             return "k_decode_lean<32, %d>" % (2 if unit == 2 else 1)
         return "k_decode_lean<%d>" % {0: 64, 1: 32, 2: 16}.get(half, 32)

@@ -464,8 +464,8 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         /* batches that fill the GPU: the loop that gathers its stores (yeast_trip.h; YEAST_MERGE 2: every output byte
            through a ring in LDS and out in complete 16-byte chunks, 47.6 ms against 57.4 at 65,536 streams; 1: one store
            per command, 52.6 ms; 0: the plain loop, faster at 32,768 streams and fewer, where a wavefront has its SIMD to
-           itself and every LDS round trip shows) */
-        const int merge = env_int("YEAST_MERGE", n > (size_t)d.cus * 192 ? 2 : 0);
+           itself and every LDS round trip shows: 43.2 against 45.4 ms; the two meet at 40,960 streams) */
+        const int merge = env_int("YEAST_MERGE", n >= (size_t)d.cus * 160 ? 2 : 0);
         e = ysl_launch(&p, half, merge, groups, st);
         p.order = nullptr;
         p.debug = 0;

@@ -15,8 +15,9 @@
 #ifndef YS_MAX_OCC
 #define YS_MAX_OCC 4 /* blocks per CU the register budget is cut for (experiments: 2 leaves S = 16 unspilled) */
 #endif
-/* UNIT: the loop that stores a copy's last piece and the literals behind it as one unit (yeast_trip.h): for batches that
-   keep every SIMD busy with two wavefronts */
+/* UNIT: the form of the loop's stores (yeast_trip.h).  0: a store per piece and per literal; 1: a copy's last piece and the
+   literals behind it as one unit; 2: chunk write-behind through a ring in LDS, for batches that keep every SIMD busy with
+   two wavefronts */
 template <int S, int UNIT = 0>
 __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) void k_decode_lean(ys_params p)
 {

@@ -20,7 +20,7 @@ body = "\n".join(l for l in open('gpurun_out/r02/lean_profile.txt').read().split
 open('profiles/r02/lean_trip_profile.txt', 'w').write(hdr + body)
 rows = []
 for l in open('gpurun_out/r02/series.txt'):
-    m = re.match(r"(\d+)\s+kernel (\S+) ([\d.]+) ms\s+step_ms ([\d.]+)\s+GB/s ([\d.]+)", l)
+    m = re.match(r"(\d+)\s+kernel (.+?) ([\d.]+) ms\s+step_ms ([\d.]+)\s+GB/s ([\d.]+)", l)
     if m:
         rows.append({"streams": int(m.group(1)), "kernel": m.group(2), "kernel_ms": float(m.group(3)), "step_ms": float(m.group(4)), "GBps": float(m.group(5))})
 json.dump({"what": "single-GPU time of one batch over batch sizes (cfg2 streams, tools/series.sh): the cost of one shard of a strong-scaling run; a launch lasts as long as its longest stream, so 8,192 streams take about three quarters of the time of 65,536",
