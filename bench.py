@@ -117,8 +117,10 @@ def kernel_label(n, lanes):
     if lanes == 65:
         return "k_decode_wave"
     if lanes == 1:
-        half = int(os.environ.get("YEAST_HALF", "1"))
         unit = int(os.environ.get("YEAST_MERGE", "2" if n >= 40960 else "0"))  # the loop that gathers its stores: large batches
+        half = int(os.environ.get("YEAST_HALF", "0" if unit == 2 and n > 65536 else "1"))  # more than one round: full wavefronts
+        if half == 0 and unit == 2:
+            return "k_decode_lean<64, 2>"
         if half == 1 and unit:
             return "k_decode_lean<32, %d>" % (2 if unit == 2 else 1)
         return "k_decode_lean<%d>" % {0: 64, 1: 32, 2: 16}.get(half, 32)

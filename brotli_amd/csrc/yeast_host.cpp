@@ -431,9 +431,13 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     /* half-filled wavefronts, two per SIMD: 65,536 streams per 256 CUs are one round; larger batches take
        further rounds, the wavefronts that finish early picking up the shorter streams (107 ms against 116 ms
        in full wavefronts at 131,072 streams, 213 against 223 at 262,144) */
-    const int half = flat ? env_int("YEAST_HALF", 1) : 0;
+    /* with the write-behind form of the loop (YEAST_MERGE 2, below) full wavefronts win as soon as there is more than
+       one round: 82.8 against 88.6 ms at 131,072 streams, 162.7 against 173.7 at 262,144 (one round: 49.3 against 47.6) */
+    const int merge = flat ? env_int("YEAST_MERGE", n >= (size_t)d.cus * 160 ? 2 : 0) : 0;
+    const int half = flat ? env_int("YEAST_HALF", merge == 2 && n > (size_t)d.cus * 256 ? 0 : 1) : 0;
     unsigned per_block = 256u / (unsigned)lanes / (half == 2 ? 4u : half ? 2u : 1u);
-    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : 2) : 4);
+    /* full wavefronts with the ring: 110 KB of LDS per block, one block per CU */
+    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : half == 0 && merge == 2 ? 1 : 2) : 4);
     size_t want_blocks = (n + per_block - 1) / per_block;
     size_t max_blocks = (size_t)d.cus * blocks_per_cu;
     unsigned blocks = (unsigned)(want_blocks < max_blocks ? want_blocks : max_blocks);
@@ -465,7 +469,6 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
            through a ring in LDS and out in complete 16-byte chunks, 47.6 ms against 57.4 at 65,536 streams; 1: one store
            per command, 52.6 ms; 0: the plain loop, faster at 32,768 streams and fewer, where a wavefront has its SIMD to
            itself and every LDS round trip shows: 43.2 against 45.4 ms; the two meet at 40,960 streams) */
-        const int merge = env_int("YEAST_MERGE", n >= (size_t)d.cus * 160 ? 2 : 0);
         e = ysl_launch(&p, half, merge, groups, st);
         p.order = nullptr;
         p.debug = 0;

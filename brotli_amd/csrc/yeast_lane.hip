@@ -176,6 +176,8 @@ extern "C" int ysl_launch(const ys_params *p, int half, int merge, unsigned stre
 {
     if (half == 1 && merge == 2)
         return launch_lean_t<32, 2>(*p, streams, (hipStream_t)stream);
+    if (half == 0 && merge == 2)
+        return launch_lean_t<64, 2>(*p, streams, (hipStream_t)stream);
     if (half == 1 && merge)
         return launch_lean_t<32, 1>(*p, streams, (hipStream_t)stream);
     if (half == 2) /* quarter-filled wavefronts (a test and measurement shape: the kernel needs ~196 registers with its

@@ -50,7 +50,7 @@ struct TripLds {
     u32x4 piece[64];
     u32x4 unit[64]; /* UNIT form of the loop: the output unit being put together (a piece and the literals behind it);
                        RING form: where a piece taken from the ring waits for the next trip */
-    u8 ring[32 * YT_RING_STRIDE + 16]; /* RING form: the last 64 bytes of each stream's output (see run_trip_fn) */
+    u8 ring[S * YT_RING_STRIDE + 16]; /* RING form: the last 64 bytes of each stream's output (see run_trip_fn) */
 };
 
 /* LDS image shared by the wavefronts of a block */
@@ -164,7 +164,6 @@ NOINL TripOut run_trip_fn(TripIn a)
        fifteen bytes is.  What is left at the end of the loop goes out byte by byte, so nothing is written beyond the
        output region and the loop needs no special case for the region's last bytes. */
     constexpr bool RING = (SF & 0x200) != 0;
-    static_assert(!RING || S == 32, "the ring is laid out for 32 streams per wavefront");
     LAS TripLds<S> *wl = (LAS TripLds<S> *)a.wl;
     LAS const TripShared *ts = a.ts;
     const u32 slot = threadIdx.x & 63;
@@ -255,7 +254,7 @@ NOINL TripOut run_trip_fn(TripIn a)
     u32 wn = 0;         /* UNIT: bytes in the unit that is being put together; RING: bytes in the ring that are not in memory yet */
     bool pl = false;    /* RING: the piece asked for on the last trip came from the ring and waits in wl->unit */
     const u32 base_lo = (u32)(uintptr_t)a.outp; /* RING: where this call's output starts: byte k of it lives at ring offset k & 63 */
-    LAS u8 *const rb = (LAS u8 *)wl->ring + (slot & 31) * YT_RING_STRIDE + 32;
+    LAS u8 *const rb = (LAS u8 *)wl->ring + (slot & (S - 1)) * YT_RING_STRIDE + 32;
     if constexpr (RING) { /* the output of earlier meta-blocks that a copy may reach through the ring */
         u64 got0 = (u64)(a.outp - a.out);
         u32 k = got0 < 48 ? (u32)got0 : 48u;

@@ -190,8 +190,8 @@ def test_randomly_assembled_streams(lanes, monkeypatch):
         assert r[1] == out, i
 
 
-@pytest.mark.parametrize("merge", [1, 2])
-def test_batch_kernel_with_one_store_per_command(monkeypatch, merge):
+@pytest.mark.parametrize("merge,half", [(1, 1), (2, 1), (2, 0)])
+def test_batch_kernel_with_one_store_per_command(monkeypatch, merge, half):
     # the forms of the batch kernel that gather the stores of the output (YEAST_MERGE 1: a copy's last piece and the
     # literals behind it stored as one unit, the form large batches get; 2: every byte through a ring in LDS and out in
     # complete 16-byte chunks, near copies served from the ring): forced here
@@ -200,6 +200,7 @@ def test_batch_kernel_with_one_store_per_command(monkeypatch, merge):
     import random_plans as R
     monkeypatch.setenv("YEAST_FORCE_LANES", "1")
     monkeypatch.setenv("YEAST_MERGE", str(merge))
+    monkeypatch.setenv("YEAST_HALF", str(half))  # 0: full wavefronts, what batches of more than one round get
     cr = H.load_json("crafted.json")
     cases = [bytes.fromhex(v["hex"]) for v in cr.values()]
     cases += [comp for _, comp, _ in H.testdata_pairs()]

@@ -77,5 +77,5 @@ def test_bench_strong_scaling_shards_cover_the_batch_once():
     # the label in the bench line follows the dispatcher's rule (include/yeast_batch.h: lanes_per_stream 0)
     for k in ("YEAST_LANES", "YEAST_HALF", "YEAST_MERGE"):
         os.environ.pop(k, None)
-    assert bench.kernel_label(65536, 0) == "k_decode_lean<32, 2>" and bench.kernel_label(6144, 0) == "k_decode_lean<32>"
+    assert bench.kernel_label(65536, 0) == "k_decode_lean<32, 2>" and bench.kernel_label(131072, 0) == "k_decode_lean<64, 2>" and bench.kernel_label(6144, 0) == "k_decode_lean<32>"
     assert bench.kernel_label(6143, 0) == "k_decode_wave" and bench.kernel_label(100, 64) == "k_decode<64>"

@@ -28,14 +28,15 @@ for seed in range(first, first + seeds):
             extra.append((bytes(b), None))
         ss = ss + extra
     want = [H.oracle_yeast(s) for s, _ in ss]
-    for lanes, merge in ((1, 0), (1, 1), (1, 2), (65, 0)):
+    for lanes, merge, half in ((1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 2, 0), (65, 0, 1)):
         os.environ["YEAST_FORCE_LANES"] = str(lanes)
         os.environ["YEAST_MERGE"] = str(merge)
+        os.environ["YEAST_HALF"] = str(half)
         res = ba.yeast_batch([s for s, _ in ss], ba.CHECK_NONE)
         for i, (w, r) in enumerate(zip(want, res)):
             if (r[0], r[2], r[3], r[1]) != (w[0], w[1], w[2], w[3]):
                 bad += 1
-                print("MISMATCH seed %d stream %d lanes %d merge %d: gpu %s oracle %s" % (seed, i, lanes, merge, (r[0], r[2], r[3]), w[:3]), flush=True)
+                print("MISMATCH seed %d stream %d lanes %d merge %d half %d: gpu %s oracle %s" % (seed, i, lanes, merge, half, (r[0], r[2], r[3]), w[:3]), flush=True)
     print("seed %d: %d streams, %.1f s" % (seed, per, time.time() - t0), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
