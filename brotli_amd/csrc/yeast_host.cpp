@@ -428,9 +428,8 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     const bool flat = lanes == 1;
     /* one stream per lane: half-filled wavefronts (two per SIMD, the default), full ones (0) or
        quarter-filled ones (2) */
-    /* half-filled wavefronts, two per SIMD: 65,536 streams per 256 CUs are one round; larger batches take
-       further rounds, the wavefronts that finish early picking up the shorter streams (107 ms against 116 ms
-       in full wavefronts at 131,072 streams, 213 against 223 at 262,144) */
+    /* half-filled wavefronts, two per SIMD: 65,536 streams per 256 CUs are one round (with the plain loop larger
+       batches were better off in them too: 107 ms against 116 ms in full wavefronts at 131,072 streams) */
     /* with the write-behind form of the loop (YEAST_MERGE 2, below) full wavefronts win as soon as there is more than
        one round: 82.8 against 88.6 ms at 131,072 streams, 162.7 against 173.7 at 262,144 (one round: 49.3 against 47.6) */
     const int merge = flat ? env_int("YEAST_MERGE", n >= (size_t)d.cus * 160 ? 2 : 0) : 0;
