@@ -6,17 +6,19 @@ One step = one pass of the hot path over one batch: decode every stream of the b
 for N > 1 -- all-gather the 32-byte result records over RCCL.  Inputs are resident in HBM before
 the timed region starts.
 
-Workload (config.workload = "cfg2"): 65,536 independent streams per GPU, each decoding to 65,536
-bytes (English text, brotli quality 11, lgwin 22), tiled from the 256 distinct committed streams of
-tests/golden/cfg2_streams.bin in a fixed pseudo-random order.  Scaling is weak: every rank decodes
-its own 65,536-stream shard; value = bytes decoded by all ranks / max-over-ranks time.
+Workload (config.workload = "cfg2"): 65,536 independent streams, each decoding to 65,536 bytes (English
+text, brotli quality 11, lgwin 22), tiled from the 256 distinct committed streams of
+tests/golden/cfg2_streams.bin in a fixed pseudo-random order.
 
---scaling strong (BASELINE.json config 3, "same batch sharded"): ONE batch of --streams streams for the
-whole job, cut into contiguous shards by compressed bytes (brotli_amd.sharding.balanced_shards), one
-per rank; the records are all-gathered, value = bytes of the whole batch / max-over-ranks time.  The
-line then carries "strong_scaling_floor": the single-GPU kernel time over batch sizes
-(profiles/r02/stream_series.json), i.e. what a shard of that size costs -- a launch lasts as long as
-its longest stream, so a shard of 8,192 streams is not 8 x faster than the batch of 65,536.
+N = 1: BASELINE.json config 2, the whole batch on one GPU ("scaling": "weak" trivially).
+N > 1: BASELINE.json config 3, "same batch sharded" -- the default is --scaling strong: ONE batch of
+--streams streams for the whole job, cut into contiguous shards by compressed bytes
+(brotli_amd.sharding.balanced_shards), one per rank; the records are all-gathered inside the step,
+value = bytes of the whole batch / max-over-ranks time.  The line then carries "weak_scaling" (every
+rank its own --streams batch, from a second timed loop) and "strong_scaling_floor": the single-GPU
+kernel time over batch sizes (profiles/r0N/stream_series.json), i.e. what a shard of that size costs
+-- a launch lasts as long as its longest stream, so a shard of 8,192 streams is not 8 x faster than
+the batch of 65,536.  --scaling weak asks for the weak-scaling run alone.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through
 python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -110,23 +112,6 @@ def measured_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def kernel_label(n, lanes):
-    """The decode kernel the library's dispatcher picks (yeast_host.cpp enqueue())."""
-    env = int(os.environ.get("YEAST_LANES", "0"))
-    lanes = lanes or env or (1 if n >= 6144 else 65)
-    if lanes == 65:
-        return "k_decode_wave"
-    if lanes == 1:
-        unit = int(os.environ.get("YEAST_MERGE", "2" if n >= 40960 else "0"))  # the loop that gathers its stores: large batches
-        half = int(os.environ.get("YEAST_HALF", "0" if unit == 2 and n > 65536 else "1"))  # more than one round: full wavefronts
-        if half == 0 and unit == 2:
-            return "k_decode_lean<64, 2>"
-        if half == 1 and unit:
-            return "k_decode_lean<32, %d>" % (2 if unit == 2 else 1)
-        return "k_decode_lean<%d>" % {0: 64, 1: 32, 2: 16}.get(half, 32)
-    return "k_decode<%d>" % lanes
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,8 +123,10 @@ def main():
     ap.add_argument("--order", default="shuffled", choices=["shuffled", "wave", "same"],
                     help="diagnostic stream layouts (see build_order); the metric is quoted on shuffled")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="streams for the host baseline (0 = skip)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --streams per GPU; strong: --streams for the whole job, sharded over the ranks")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: --streams per GPU; strong: --streams for the whole job, sharded over the ranks "
+                         "(BASELINE config 3).  Default: strong when launched on more than one GPU, else weak")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1, strong scaling: skip the second (weak-scaling) timed loop")
     args = ap.parse_args()
 
     import torch
@@ -160,64 +147,80 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     meta, distinct = load_distinct()
-    strong = args.scaling == "strong"
-    sizes = None
-    if strong:
-        # one batch for the whole job (the same on every rank), this rank's contiguous shard of it
-        from brotli_amd.sharding import balanced_shards
-        full = build_order(args.streams, len(distinct), 0x5EED, args.order)
-        shards = balanced_shards([len(distinct[j]) for j in full], world)
-        lo, hi = shards[rank]
-        order = full[lo:hi]
-        sizes = [(b - a) * 32 for a, b in shards]
-        if hi == lo:
-            raise SystemExit("bench: fewer streams than ranks")
-    else:
-        order = build_order(args.streams, len(distinct), 0x5EED + rank, args.order)
-        sizes = [len(order) * 32] * world  # every rank decodes as many streams: no exchange of counts in the step
-    n = len(order)
-    streams = [distinct[j] for j in order]
-    batch = DeviceBatch(streams, [65536] * n, device=dev)
-    want_got = np.array([meta[j]["got"] for j in order], dtype=np.uint64)
-    want_used = np.array([meta[j]["len"] for j in order], dtype=np.uint64)
-    want_chk = np.array([int(meta[j][{1: "crc32c", 2: "xxh32", 3: "xxh64"}.get(args.check, "xxh64")], 16)
-                         for j in order], dtype=np.uint64)
-    del streams
-
-    def step():
-        batch.decode(check=args.check, lanes=args.lanes)
-        if dist is not None:
-            return all_gather_records(batch.rec, dist, sizes=sizes)
-        return batch.rec
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    strong = scaling == "strong"
+    verified = [True]
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # verify once, outside the timed region: every stream decoded, sizes and checks as the fixtures say
-    r = batch.records()
-    ok = (r["rc"] == 0).all() and (r["got"] == want_got).all() and (r["used"] == want_used).all()
-    if args.check:
-        ok = ok and (r["check"] == want_chk).all()
-    if not ok and not os.environ.get("BENCH_NOVERIFY"):  # BENCH_NOVERIFY: timing of deliberately broken experiment builds
-        bad = int(np.argmax((r["rc"] != 0) | (r["got"] != want_got) | (r["used"] != want_used) | ((r["check"] != want_chk) & bool(args.check))))
-        raise SystemExit("bench: decode results do not match the fixtures (first bad stream %d: %s)" % (bad, r[bad]))
+    def prepare(strong_mode):
+        """The batch of one mode, resident in HBM, with what the fixtures say about every stream of it."""
+        full = None
+        if strong_mode:
+            # one batch for the whole job (the same on every rank), this rank's contiguous shard of it
+            from brotli_amd.sharding import balanced_shards
+            full = build_order(args.streams, len(distinct), 0x5EED, args.order)
+            shards = balanced_shards([len(distinct[j]) for j in full], world)
+            lo, hi = shards[rank]
+            order = full[lo:hi]
+            sizes = [(b - a) * 32 for a, b in shards]
+            if hi == lo:
+                raise SystemExit("bench: fewer streams than ranks")
+        else:
+            order = build_order(args.streams, len(distinct), 0x5EED + rank, args.order)
+            sizes = [len(order) * 32] * world  # every rank decodes as many streams: no exchange of counts in the step
+        n = len(order)
+        batch = DeviceBatch([distinct[j] for j in order], [65536] * n, device=dev)
+        want = {"got": np.array([meta[j]["got"] for j in order], dtype=np.uint64),
+                "used": np.array([meta[j]["len"] for j in order], dtype=np.uint64),
+                "chk": np.array([int(meta[j][{1: "crc32c", 2: "xxh32", 3: "xxh64"}.get(args.check, "xxh64")], 16)
+                                 for j in order], dtype=np.uint64)}
+        return {"batch": batch, "order": order, "full": full, "sizes": sizes, "n": n, "want": want}
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(m):
+        """W warm-up steps, the fixture check outside the timed region, K timed steps: seconds (max over ranks)."""
+        batch, sizes, want = m["batch"], m["sizes"], m["want"]
+
+        def step():
+            batch.decode(check=args.check, lanes=args.lanes)
+            if dist is not None:
+                return all_gather_records(batch.rec, dist, sizes=sizes)
+            return batch.rec
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        m["kernel"] = ba.lib().yeast_last_kernel().decode()  # what the library's dispatcher launched for this batch
+        # verify once, outside the timed region: every stream decoded, sizes and checks as the fixtures say
+        r = batch.records()
+        ok = (r["rc"] == 0).all() and (r["got"] == want["got"]).all() and (r["used"] == want["used"]).all()
+        if args.check:
+            ok = ok and (r["check"] == want["chk"]).all()
+        if not ok:
+            verified[0] = False
+            if not os.environ.get("BENCH_NOVERIFY"):  # BENCH_NOVERIFY: timing of deliberately broken experiment builds
+                bad = int(np.argmax((r["rc"] != 0) | (r["got"] != want["got"]) | (r["used"] != want["used"]) |
+                                    ((r["check"] != want["chk"]) & bool(args.check))))
+                raise SystemExit("bench: decode results do not match the fixtures (first bad stream %d: %s)" % (bad, r[bad]))
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    m = prepare(strong)
+    dt = timed(m)
+    batch, n, order, full = m["batch"], m["n"], m["order"], m["full"]
+    want_got, want_used = m["want"]["got"], m["want"]["used"]
 
     # kernel-level timing for the roofline: HIP events on the stream the kernels are launched on,
     # decode only (no check, no gather), K launches
@@ -250,20 +253,27 @@ def main():
     value = job_out / (dt / args.steps) / 1e9
     copy_gbs = measured_copy_gbs(torch, dev) if rank == 0 else None
     achieved = algo / (k_ms * 1e-3) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/prof_summary.py from the PMC passes
+    kernel = m["kernel"]
+    # HBM bytes per launch from the PMC passes (tools/prof_summary.py writes the file).  Only quoted when it was
+    # measured on this batch size AND on the kernel that ran just now: a figure of another kernel is no figure.
+    traffic, traffic_note = None, None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf):
         try:
             t = json.load(open(tf))
-            if t.get("streams") == n:
+            if t.get("streams") == n and kernel and kernel in str(t.get("kernel", "")):
                 traffic = t.get("bytes_per_launch")
+                traffic_note = {k: t[k] for k in ("fetch_bytes", "write_bytes", "fetch_factor", "source") if k in t}
+            elif t.get("streams") == n:
+                traffic_note = "profiles/hbm_traffic.json is of kernel %r, this run launched %r: not quoted" % (t.get("kernel"), kernel)
         except Exception:
             traffic = None
 
     line = {
         "metric": "decompressed GB/s (whole node), batched 64 KiB brotli streams",
         "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "verified": verified[0],
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "cfg2: %s x 65,536 B out, q11 lgwin22 English text, %d distinct "
                                "streams tiled in seeded order; decode + %s check%s"
@@ -272,19 +282,21 @@ def main():
                                   len(distinct), {0: "no", 1: "CRC-32C", 2: "XXH32", 3: "XXH64"}[args.check],
                                   " + RCCL all-gather of records" if world > 1 else ""),
                    "streams_per_gpu": n, "order": args.order, "out_bytes_per_gpu": out_bytes, "in_bytes_per_gpu": in_bytes,
-                   "lanes_per_stream": args.lanes or int(os.environ.get("YEAST_LANES", "0")) or (1 if n >= 6144 else 65),
+                   "lanes_per_stream": 1 if "lean" in kernel else 65 if "wave" in kernel else args.lanes,
                    "parallelism": "%d independent shards" % world},
-        "roofline": {"bound": "hbm", "kernel": kernel_label(n, args.lanes), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "algorithmic_bytes_per_launch": algo, "kernel_ms": k_ms, "check_kernel_ms": c_ms,
                      "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None},
     }
-    series = os.path.join(ROOT, "profiles", "r02", "stream_series.json")
+    series = os.path.join(ROOT, "profiles", "r03", "stream_series.json")
+    if not os.path.exists(series):
+        series = os.path.join(ROOT, "profiles", "r02", "stream_series.json")
     if os.path.exists(series):
         # single-GPU kernel time over batch sizes: what one shard of a strong-scaling run costs
         fl = json.load(open(series))
-        line["strong_scaling_floor"] = {"what": fl["what"], "source": "profiles/r02/stream_series.json",
+        line["strong_scaling_floor"] = {"what": fl["what"], "source": os.path.relpath(series, ROOT),
                                         "kernel_ms_by_streams": {str(r["streams"]): r["kernel_ms"] for r in fl["rows"]}}
     if rank == 0 and world == 1 and args.cpu_sample:
         # threads: this job's CPU share (OMP_NUM_THREADS is set to it on the GPU box, where os.cpu_count()
@@ -296,6 +308,17 @@ def main():
         line["cpu_baseline"]["host_cpus"] = os.cpu_count()
         line["cpu_baseline"]["cpu_share"] = share
         line["cpu_baseline_1thread"] = cpu_baseline(distinct, order, 1, max(256, sample // 16))
+    if strong and world > 1 and not args.no_weak:
+        # the weak-scaling figure beside it (every rank its own --streams batch), from a second timed loop
+        del batch
+        m["batch"] = None
+        torch.cuda.empty_cache()
+        mw = prepare(False)
+        dtw = timed(mw)
+        line["weak_scaling"] = {"value": float(mw["want"]["got"].sum()) * world / (dtw / args.steps) / 1e9, "unit": "GB/s",
+                                "ms_per_step": dtw / args.steps * 1e3, "streams_per_gpu": mw["n"],
+                                "what": "every rank decodes its own batch of --streams streams; same step otherwise"}
+        line["verified"] = verified[0]
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

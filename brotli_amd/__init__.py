@@ -97,6 +97,7 @@ def lib() -> ctypes.CDLL:
         L.XXH64.restype = ctypes.c_ulonglong
         L.XXH64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_ulonglong]
         L.yeast_last_error.restype = ctypes.c_char_p
+        L.yeast_last_kernel.restype = ctypes.c_char_p
         L.yeast_device_count.restype = ctypes.c_int
         L.yeast_debug_table.restype = ctypes.c_void_p
         L.yeast_debug_table.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]

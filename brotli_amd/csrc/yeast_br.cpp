@@ -103,11 +103,22 @@ uintmax_t cut_check(unsigned kind, uintmax_t v)
         v &= width == 2 ? 0xffff : 0xff;
     return v;
 }
+/* The check functions keep the reference's signatures and so have no error value of their own: a call that could
+   not run on the GPU returns 0 and is counted (yeast_check_error()).  Here every use asks, and a value that was
+   not computed ends the call with -1 instead of being compared or written. */
+uintmax_t check_value(unsigned kind, const void *p, size_t n) /* kind: low three bits of a content mask */
+{
+    (void)yeast_check_error();
+    uintmax_t v = kind < 3 ? XXH32(p, n, 0) : kind == 3 ? XXH64(p, n, 0) : crc32c(0, p, n);
+    if (yeast_check_error())
+        throw Fail{-1};
+    return v;
+}
+unsigned xxh32_of(const void *p, size_t n) { return (unsigned)check_value(2, p, n); }
 uintmax_t check_of(unsigned kind, const void *p, size_t n)
 {
     kind &= 7;
-    uintmax_t v = kind < 3 ? XXH32(p, n, 0) : kind == 3 ? XXH64(p, n, 0) : crc32c(0, p, n);
-    return cut_check(kind, v);
+    return cut_check(kind, check_value(kind, p, n));
 }
 unsigned batch_kind(unsigned mask) /* content mask check -> yeast_batch check kind */
 {
@@ -156,7 +167,7 @@ Header read_header(Cursor &c, bool first, size_t want_off)
                 throw Fail{3};
         }
         if (extra & EXTRA_CHECK) { /* XXH32 of the header so far, low two bytes: broad.c:231-234 */
-            unsigned chk = XXH32(c.buf + start, c.next - start, 0) & 0xffff;
+            unsigned chk = xxh32_of(c.buf + start, c.next - start) & 0xffff;
             if (chk != c.getn(2))
                 throw Fail{3};
         }
@@ -829,7 +840,7 @@ extern "C" int yeast_braid(size_t n, void const *const *br, const size_t *len, v
                     if (extra & EXTRA_CHECK) {
                         (void)getc_();
                         (void)getc_();
-                        unsigned x = head ? XXH32(o.data() + here, o.size() - here, 0) & 0xffff : 0;
+                        unsigned x = head ? xxh32_of(o.data() + here, o.size() - here) & 0xffff : 0;
                         o.push_back((uint8_t)(x & 0xff));
                         o.push_back((uint8_t)(x >> 8));
                     }
@@ -852,7 +863,9 @@ extern "C" int yeast_braid(size_t n, void const *const *br, const size_t *len, v
                 } else if (any)
                     total = -1;
             }
-        } catch (Fail &) { /* "-- skipping": braid.c:392-396 */
+        } catch (Fail &f) { /* "-- skipping": braid.c:392-396 */
+            if (f.code < 0) /* a header check could not be computed: no output rather than a wrong one */
+                return -1;
             o.resize(keep_o);
             checks.resize(keep_c);
             last = keep_last;
@@ -875,8 +888,13 @@ extern "C" int yeast_braid(size_t n, void const *const *br, const size_t *len, v
         put_bvar(o, off - last);
     if (total != -1)
         put_bvar(o, (uintmax_t)total);
-    if (count > 1)
-        put_little(o, XXH32(checks.data(), checks.size(), 0), 4);
+    if (count > 1) {
+        try {
+            put_little(o, xxh32_of(checks.data(), checks.size()), 4);
+        } catch (Fail &) {
+            return -1;
+        }
+    }
     if (trail != (CONTENT_TRAIL | 7))
         o.push_back((uint8_t)trail);
     if (hand_over(o, out, out_len))

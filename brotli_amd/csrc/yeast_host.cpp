@@ -69,6 +69,10 @@ static int fail(const char *what, hipError_t e)
     } while (0)
 
 extern "C" const char *yeast_last_error(void) { return t_err; }
+/* which decode kernel the last batch call of this thread was given (as rocprofv3 prints its name, without the
+   argument list): a measurement aid, so that a bench line names the kernel that ran and not one it guesses */
+static thread_local char t_kernel[64] = "";
+extern "C" const char *yeast_last_kernel(void) { return t_kernel; }
 extern "C" int yeast_check_error(void)
 {
     int n = t_check_failed;
@@ -419,6 +423,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
             return -1;
         p.ws = (u8 *)d.ws.p;
         p.ws_stride = stride;
+        snprintf(t_kernel, sizeof(t_kernel), "k_decode_wave");
         e = ysw_launch(&p, slot_entries, rootcaps, blocks, st);
         if (e)
             return fail("decode launch", (hipError_t)e);
@@ -468,12 +473,21 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
            through a ring in LDS and out in complete 16-byte chunks, 47.6 ms against 57.4 at 65,536 streams; 1: one store
            per command, 52.6 ms; 0: the plain loop, faster at 32,768 streams and fewer, where a wavefront has its SIMD to
            itself and every LDS round trip shows: 43.2 against 45.4 ms; the two meet at 40,960 streams) */
+        {
+            int S = half == 2 ? 16 : half ? 32 : 64, form = (half == 0 || half == 1) && merge == 2 ? 2 : half == 1 && merge ? 1 : 0;
+            if (form)
+                snprintf(t_kernel, sizeof(t_kernel), "k_decode_lean<%d, %d>", S, form);
+            else
+                snprintf(t_kernel, sizeof(t_kernel), "k_decode_lean<%d, 0>", S);
+        }
         e = ysl_launch(&p, half, merge, groups, st);
         p.order = nullptr;
         p.debug = 0;
     }
-    else
+    else {
+        snprintf(t_kernel, sizeof(t_kernel), "k_decode<%d, %s>", lanes, cmp ? "true" : "false");
         e = ys_launch_decode(&p, lanes, cmp, groups, st);
+    }
     if (e)
         return fail("decode launch", (hipError_t)e);
     }
@@ -549,7 +563,15 @@ extern "C" int yeast_batch_device_static(const void *d_src, const uint64_t *d_sr
         return 0;
     Device &d = g_dev[id];
     hipStream_t st = (hipStream_t)hip_stream;
-    if (d.have_ev && d.last_st != st) /* calls on one device share the static workspace too */
+    /* Calls on one device share the static workspace, so a call on another stream is put behind the last one.
+       Not while the stream is being captured into a HIP graph: an event recorded outside the capture cannot be
+       waited for inside it (the capture would be invalidated), and one recorded inside belongs to the graph.  A
+       captured call is ordered by whoever launches the graph: replays must not overlap other calls on the device. */
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) != hipSuccess)
+        cap = hipStreamCaptureStatusNone;
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && d.have_ev && d.last_st != st)
         HIPCK(hipStreamWaitEvent(st, d.last_ev, 0));
     ys_params p;
     memset(&p, 0, sizeof(p));
@@ -566,7 +588,7 @@ extern "C" int yeast_batch_device_static(const void *d_src, const uint64_t *d_sr
     int e = ys_launch_decode_static(&p, id, st);
     if (!e && check_kind)
         e = ys_launch_check((const u8 *)d_dst, d_dst_off, (ys_record *)d_rec, (unsigned)n, check_kind, 0, st);
-    if (hipEventRecord(d.last_ev, st) == hipSuccess) {
+    if (!capturing && hipEventRecord(d.last_ev, st) == hipSuccess) {
         d.last_st = st;
         d.have_ev = true;
     }
@@ -675,6 +697,10 @@ static int run_host_batch_impl(size_t n, void const *const *src, const size_t *l
 static int run_host_batch(size_t n, void const *const *src, const size_t *len, std::vector<ys_record> &rec,
                           void **out, unsigned check_kind, int cmp, const void *expected, size_t have)
 {
+    /* out[] is a pure output: whatever the caller left in it is never looked at (and never freed) */
+    if (out)
+        for (size_t i = 0; i < n; i++)
+            out[i] = nullptr;
     int e = run_host_batch_impl(n, src, len, rec, out, check_kind, cmp, expected, have);
     if (e && out) {
         (void)hipStreamSynchronize(nullptr);

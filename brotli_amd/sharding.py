@@ -46,8 +46,7 @@ def all_gather_records(local, dist=None, group=None, sizes=None):
     if dist is None:
         import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
-        return local.clone()
+    # (no shortcut for a group of one: the collective runs, so a one-GPU box exercises RCCL too)
     if sizes is None:
         count = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
         counts = [torch.zeros_like(count) for _ in range(world)]

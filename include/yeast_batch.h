@@ -85,10 +85,12 @@ int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, void *d_dst
  *   - at most 16,384 streams per call; more is refused with -1 and a message (yeast_last_error());
  *   - sixteen wavefronts decode (one stream each at a time, worst-case table arenas, so every valid stream
  *     decodes): meant for modest batches, not for throughput;
- *   - every call on a GPU uses that GPU's one array: the library orders its own calls on a device one after the
- *     other (across streams too), but two processes' or two libraries' kernels are not its business, and a
- *     captured graph that holds this call must not be replayed while another call of the library runs on the
- *     same GPU.
+ *   - every call on a GPU uses that GPU's one array, so calls that overlap on one GPU race on it.  Ordinary
+ *     (eager) calls the library orders itself, one after the other, across streams too (an event per device).
+ *     On a stream that is being captured into a HIP graph it neither waits for nor records that event (an event
+ *     from outside the capture would invalidate it): the captured call, and every replay of the graph, is the
+ *     caller's to order against other calls of the library on the same GPU.  Other processes' kernels are not
+ *     the library's business either.
  */
 int yeast_init(void); /* set up the current device (allocates its constant tables once); 0 or -1 */
 int yeast_batch_device_static(const void *d_src, const uint64_t *d_src_off, void *d_dst, const uint64_t *d_dst_off,
@@ -112,6 +114,9 @@ int yeast_check_device(const void *d_dst, const uint64_t *d_dst_off, yeast_recor
 uint32_t crc32c(uint32_t crc, void const *buf, size_t len);
 unsigned int XXH32(const void *input, size_t len, unsigned int seed);
 unsigned long long XXH64(const void *input, size_t len, unsigned long long seed);
+/* Measurement aid: the name of the decode kernel the calling thread's last batch call launched ("k_decode_lean<32, 2>",
+   "k_decode_wave", ...), as a profiler prints it; "" before any call. */
+const char *yeast_last_kernel(void);
 int yeast_check_error(void); /* check-value calls of this thread that failed since the last call of this; 0 = none */
 
 /*

@@ -60,6 +60,26 @@ def test_testdata_corpus_compare_mode():
 
 KERNELS = [64, 65, 1]  # cooperative, wavefront per stream (LDS tables), one stream per lane
 
+# Every form of the decode path: the cooperative kernel, the wavefront-per-stream kernel, and the batch kernel
+# (one stream per lane) in the three forms the dispatcher uses by batch size -- (YEAST_MERGE, YEAST_HALF) =
+# (0, 1) plain loop, half-filled wavefronts (small batches); (2, 1) write-behind through the LDS ring, half-filled
+# (one round: what bench.py runs at 65,536 streams); (2, 0) the same in full wavefronts (more than one round).
+FORMS = [64, 65, (1, 0, 1), (1, 2, 1), (1, 2, 0)]
+FORM_IDS = ["coop64", "wave", "lean-plain", "lean-ring-half", "lean-ring-full"]
+
+
+def use_form(monkeypatch, form):
+    """Force the kernel form; returns a small integer to seed per-form randomness with."""
+    if isinstance(form, tuple):
+        lanes, merge, half = form
+        monkeypatch.setenv("YEAST_MERGE", str(merge))
+        monkeypatch.setenv("YEAST_HALF", str(half))
+        seed = 1 + 10 * merge + half
+    else:
+        lanes, seed = form, form
+    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    return seed
+
 
 def test_compare_mode_against_the_reference_fixtures():
     # SURVEY 8c "cmp mode mismatch positions": (rc, got, used) of the real reference's yeast(cmp=1)
@@ -83,10 +103,10 @@ def test_crafted_streams_through_every_kernel(lanes, monkeypatch):
         assert (r[0], r[2], r[3], r[1].hex()) == (v["rc"], v["got"], v["used"], v["out"]), k
 
 
-@pytest.mark.parametrize("lanes", KERNELS)
-def test_misc_encoder_parameters(lanes, monkeypatch):
+@pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
+def test_misc_encoder_parameters(form, monkeypatch):
     # window bits 10..24, qualities 0..10, NPOSTFIX/NDIRECT != 0 (unpinned by testdata/)
-    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    use_form(monkeypatch, form)
     meta, streams = H.packed_streams("misc_streams")
     res = ba.yeast_batch(streams, ba.CHECK_CRC32C)
     for m, s, r in zip(meta["streams"], streams, res):
@@ -96,12 +116,12 @@ def test_misc_encoder_parameters(lanes, monkeypatch):
         assert "%08x" % r[4] == m["crc32c"]
 
 
-@pytest.mark.parametrize("lanes", KERNELS)
-def test_synthesised_streams_cfg4(lanes, monkeypatch):
+@pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
+def test_synthesised_streams_cfg4(form, monkeypatch):
     # BASELINE config 4 (tools/brosynth.py; expected values from the reference): all 121 transforms at
     # every word length, the four context modes, NPOSTFIX/NDIRECT, block switching, context map
     # styles, simple codes, overlapping copies of every short period, stored and metadata blocks
-    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    use_form(monkeypatch, form)
     meta, streams = H.packed_streams("cfg4_streams")
     res = ba.yeast_batch(streams, ba.CHECK_XXH64)
     for m, s, r in zip(meta["streams"], streams, res):
@@ -110,12 +130,12 @@ def test_synthesised_streams_cfg4(lanes, monkeypatch):
         assert r[1] == H.oracle_yeast(s)[3], m["name"]
 
 
-@pytest.mark.parametrize("lanes", KERNELS)
-def test_large_window_streams_cfg5(lanes, monkeypatch):
+@pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
+def test_large_window_streams_cfg5(form, monkeypatch):
     # BASELINE config 5: window bits 24 with 16 MiB back-references and copies of megabytes (single
     # streams: a latency case).  The batch kernel (lanes 1) hands streams of more
     # than 1 MiB of output to its retry pass, a wavefront per stream.
-    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
+    use_form(monkeypatch, form)
     meta, streams = H.packed_streams("cfg5_streams")
     for m, s in zip(meta["streams"], streams):
         (rc, out, got, used, chk), = ba.yeast_batch([s], ba.CHECK_CRC32C)
@@ -288,11 +308,10 @@ def test_check_values_known_answers():
     assert ba.xxh32(alice[:777], 12345) == o.oracle_xxh32(alice[:777], 777, 12345)
 
 
-@pytest.mark.parametrize("lanes", KERNELS)
-def test_fuzzed_streams_same_error_class_and_progress(lanes, monkeypatch):
+@pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
+def test_fuzzed_streams_same_error_class_and_progress(form, monkeypatch):
     # truncations and bit flips of real streams: rc, got, used and the partial output must agree
-    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
-    rnd = random.Random(11 + lanes)
+    rnd = random.Random(11 + use_form(monkeypatch, form))
     meta, streams = H.packed_streams("cfg2_streams")
     _, misc = H.packed_streams("misc_streams")
     cases = []
@@ -313,12 +332,11 @@ def test_fuzzed_streams_same_error_class_and_progress(lanes, monkeypatch):
     assert {2, 3} <= classes
 
 
-@pytest.mark.parametrize("lanes", [1, 65, 16])
-def test_damage_deep_inside_full_length_streams(lanes, monkeypatch):
+@pytest.mark.parametrize("form", [(1, 0, 1), (1, 2, 1), (1, 2, 0), 65, 16], ids=["lean-plain", "lean-ring-half", "lean-ring-full", "wave", "coop16"])
+def test_damage_deep_inside_full_length_streams(form, monkeypatch):
     # bit flips and cuts anywhere in whole 64 KiB streams: the failure (or the wrong but valid decode)
     # happens thousands of commands into the loop, beside healthy streams in the same wavefront
-    monkeypatch.setenv("YEAST_FORCE_LANES", str(lanes))
-    rnd = random.Random(977 + lanes)
+    rnd = random.Random(977 + use_form(monkeypatch, form))
     meta, streams = H.packed_streams("cfg2_streams")
     cases = []
     for t in range(768):
@@ -369,6 +387,57 @@ def test_full_size_batch_properties():
     r = batch.records()
     want = np.array([int(ms[j]["crc32c"], 16) for j in order], dtype=np.uint64)
     assert (r["check"] == want).all()
+
+
+@pytest.mark.parametrize("half", [1, 0], ids=["ring-half", "ring-full"])
+def test_wavefronts_take_further_streams_when_theirs_are_done(half, monkeypatch):
+    # The batch kernel holds 65,536 streams at a time (256 per CU); a wavefront whose streams are all done takes the
+    # next S from the queue (yeast_lane.hip k_decode_lean's loop).  72,000 short streams -- random plans whole and
+    # damaged, the crafted good and bad streams -- force that in both ring forms (S = 32 and S = 64); every record
+    # and every output byte against the CPU restatement.  The reused wavefront inherits LDS (ring, maps, landing
+    # slots) and workspace from the streams before, failed ones among them.
+    import random_plans as R
+    import torch
+    from brotli_amd.device import DeviceBatch
+    monkeypatch.setenv("YEAST_MERGE", "2")
+    monkeypatch.setenv("YEAST_HALF", str(half))
+    ss = [s for s, _ in R.streams(240, 4242 + half)]
+    rnd = random.Random(17 + half)
+    for s in ss[:120]:
+        b = bytearray(s)
+        if rnd.random() < 0.3:
+            b = b[:rnd.randrange(1, len(b) + 1)]
+        for _ in range(rnd.randrange(1, 4)):
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        ss.append(bytes(b))
+    ss += [bytes.fromhex(v["hex"]) for v in H.load_json("crafted.json").values()]
+    want = [H.oracle_yeast(s) for s in ss]
+    o = H.oracle()
+    chk = [o.oracle_xxh64(w[3], len(w[3]), 0) if w[0] == 0 else None for w in want]
+    n = 72000
+    pick = np.random.RandomState(9 + half).randint(0, len(ss), size=n)
+    caps = [max(want[j][1], 1) + 40 for j in pick]
+    batch = DeviceBatch([ss[j] for j in pick], caps, align=16)
+    batch.dst.fill_(0xEE)
+    batch.decode(check=ba.CHECK_XXH64, lanes=1)
+    torch.cuda.synchronize()
+    assert ba.lib().yeast_last_kernel() == (b"k_decode_lean<32, 2>" if half else b"k_decode_lean<64, 2>")
+    r = batch.records()
+    w_rc = np.array([want[j][0] for j in pick])
+    w_got = np.array([want[j][1] for j in pick], dtype=np.uint64)
+    w_used = np.array([want[j][2] for j in pick], dtype=np.uint64)
+    bad = np.nonzero((r["rc"] != w_rc) | (r["got"] != w_got) | (r["used"] != w_used))[0]
+    assert len(bad) == 0, (bad[:5], r[bad[:5]], [want[pick[i]][:3] for i in bad[:5]])
+    for i in np.nonzero(w_rc == 0)[0]:
+        assert int(r["check"][i]) == chk[pick[i]], i
+    out = batch.dst.cpu().numpy()
+    off = batch.host_dst_off
+    for i in range(n):  # partial outputs of failed streams too; and nothing written behind a stream's bytes
+        j = pick[i]
+        g = want[j][1]
+        a = int(off[i])
+        assert out[a:a + g].tobytes() == want[j][3], i
+        assert (out[a + g:int(off[i + 1])] == 0xEE).all() or want[j][0] != 0, i
 
 
 def test_shard_count_invariance():

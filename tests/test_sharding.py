@@ -74,8 +74,18 @@ def test_bench_strong_scaling_shards_cover_the_batch_once():
         assert all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
         sums = [sum(weights[a:b]) for a, b in shards]
         assert max(sums) - min(sums) <= 2 * max(weights)
-    # the label in the bench line follows the dispatcher's rule (include/yeast_batch.h: lanes_per_stream 0)
-    for k in ("YEAST_LANES", "YEAST_HALF", "YEAST_MERGE"):
-        os.environ.pop(k, None)
-    assert bench.kernel_label(65536, 0) == "k_decode_lean<32, 2>" and bench.kernel_label(131072, 0) == "k_decode_lean<64, 2>" and bench.kernel_label(6144, 0) == "k_decode_lean<32>"
-    assert bench.kernel_label(6143, 0) == "k_decode_wave" and bench.kernel_label(100, 64) == "k_decode<64>"
+
+
+def test_all_gather_records_group_of_one_runs_the_collective():
+    """No shortcut at world size 1: the same calls as on N ranks (gloo here, nccl = RCCL in the GPU tier)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, port, (6,), q))
+    p.start()
+    rank, got = q.get(timeout=120)
+    p.join(60)
+    assert got == bytes([1]) * (6 * 32)
