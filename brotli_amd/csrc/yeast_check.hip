@@ -270,6 +270,15 @@ extern "C" int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec
     return (int)hipGetLastError();
 }
 
+/* a launch over no streams: the first launch of a kernel is when the runtime loads its code object and reserves
+   what it needs on the device, and yeast_init() wants that behind it */
+extern "C" int ys_warm_check(void *stream)
+{
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, (hipStream_t)stream, (const u8 *)nullptr, (const u64 *)nullptr,
+                       (ys_record *)nullptr, 0u, 3u, (u64)0, 1);
+    return (int)hipGetLastError();
+}
+
 extern "C" int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed, u64 *out, void *stream)
 {
     hipLaunchKernelGGL(k_check_buf, dim3(1), dim3(64), 0, (hipStream_t)stream, p, len, kind, seed, out);

@@ -108,6 +108,8 @@ extern "C" int ys_static_init(int device)
 extern "C" unsigned ys_static_max_streams(void) { return YS_STATIC_MAX_STREAMS; }
 extern "C" size_t ys_static_bytes(void) { return sizeof(scratch); }
 
+__global__ void k_static_reset(u32 *counters) { counters[threadIdx.x] = 0; } /* the 256 bytes of counters */
+
 /* p: everything but the workspace and the counters filled in by the caller; n <= YS_STATIC_MAX_STREAMS */
 extern "C" int ys_launch_decode_static(const ys_params *p_in, int device, void *stream)
 {
@@ -115,7 +117,11 @@ extern "C" int ys_launch_decode_static(const ys_params *p_in, int device, void *
         return -1;
     unsigned char *ptr = g_scratch_ptr[device];
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ptr, 0, 256, st); /* the counters start at zero; the slots need no clearing */
+    /* the counters start at zero; the slots need no clearing.  By a kernel, not hipMemsetAsync: captured into a HIP
+       graph the memset node cleared the counters on the first replay only (ROCm 7.0/7.2, 256 bytes), and the second
+       replay found the queue head where the first had left it and decoded nothing */
+    hipLaunchKernelGGL(k_static_reset, dim3(1), dim3(64), 0, st, (u32 *)ptr);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return (int)e;
     ys_params p = *p_in;

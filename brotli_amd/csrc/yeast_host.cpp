@@ -42,6 +42,7 @@ int ysw_launch(const ys_params *p, unsigned slot_entries, unsigned rootcaps, uns
 int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec, unsigned n, unsigned kind, u64 seed,
                     void *stream);
 int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed, u64 *out, void *stream);
+int ys_warm_check(void *stream);
 int ys_launch_xxh_update(unsigned is64, u64 *v, const u8 *p, u64 nstripe, void *stream);
 int ys_launch_xxh_digest(unsigned is64, const u64 *v, u64 total, u64 seed, const u8 *mem, unsigned memsize, u64 *out,
                          void *stream);
@@ -248,6 +249,23 @@ static int device_get(Device **out)
         e = ys_static_init(id); /* the address of the static workspace of yeast_batch_device_static() */
         if (e)
             return fail("static workspace address", (hipError_t)e);
+        {
+            /* The first launch of a kernel is when the runtime loads its code object and reserves the kernel's private
+               memory on the device.  yeast_batch_device_static() must cause no allocation, the runtime's included, so
+               its two kernels are launched here once, over no streams. */
+            ys_params p0;
+            memset(&p0, 0, sizeof(p0));
+            p0.dict = d.d_dict;
+            p0.xforms = d.d_xf;
+            p0.xdict = d.d_xdict;
+            p0.xdict_base = d.d_xbase;
+            e = ys_launch_decode_static(&p0, id, nullptr);
+            if (!e)
+                e = ys_warm_check(nullptr);
+            if (e)
+                return fail("warm-up launch", (hipError_t)e);
+            HIPCK(hipDeviceSynchronize());
+        }
         HIPCK(hipEventCreateWithFlags(&d.last_ev, hipEventDisableTiming));
         d.ready = true;
     }

@@ -414,9 +414,25 @@ def test_wavefronts_take_further_streams_when_theirs_are_done(half, monkeypatch)
     want = [H.oracle_yeast(s) for s in ss]
     o = H.oracle()
     chk = [o.oracle_xxh64(w[3], len(w[3]), 0) if w[0] == 0 else None for w in want]
+    # output regions: a damaged stream may announce a meta-block far larger than what it gets to write, and the
+    # device call reports a region smaller than the announcement with code 5 and the size wanted in `check`
+    # (include/yeast_batch.h; the batch kernel asks at the meta-block header, before it has seen what is wrong with
+    # the rest of the header) -- sized here by asking, streams that want over 256 KiB dropped
+    need = [max(w[1], 1) + 40 for w in want]
+    for _ in range(6):
+        probe = DeviceBatch(ss, need, align=16)  # a region is as long as the distance to the next one
+        probe.decode(check=ba.CHECK_NONE, lanes=1)
+        pr = probe.records()
+        small = np.nonzero(pr["rc"] == 5)[0]
+        if len(small) == 0:
+            break
+        for j in small:
+            need[j] = int(pr["check"][j]) + 40
+    keep = [j for j in range(len(ss)) if need[j] <= (1 << 18) and pr["rc"][j] != 5]
+    assert len(keep) > 300
     n = 72000
-    pick = np.random.RandomState(9 + half).randint(0, len(ss), size=n)
-    caps = [max(want[j][1], 1) + 40 for j in pick]
+    pick = np.array(keep)[np.random.RandomState(9 + half).randint(0, len(keep), size=n)]
+    caps = [need[j] for j in pick]
     batch = DeviceBatch([ss[j] for j in pick], caps, align=16)
     batch.dst.fill_(0xEE)
     batch.decode(check=ba.CHECK_XXH64, lanes=1)

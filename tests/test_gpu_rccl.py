@@ -32,7 +32,7 @@ for sizes in (None, [b.rec.numel()]):
     torch.cuda.synchronize()
     r = out.cpu().numpy().view(RECORD_DTYPE)
     for i in range(len(streams)):
-        m = meta[(11 * i + 5) %% 256]
+        m = meta["streams"][(11 * i + 5) %% 256]
         assert (int(r["rc"][i]), int(r["got"][i]), int(r["used"][i]), int(r["check"][i])) == (0, m["got"], m["len"], int(m["xxh64"], 16)), i
 # ragged shards take the padded path: one rank, same code
 out = all_gather_records(b.rec[:96], dist)

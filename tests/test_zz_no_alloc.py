@@ -64,7 +64,7 @@ b.decode_static(check=ba.CHECK_XXH64)      # the library's first decode in this 
 torch.cuda.synchronize()
 assert torch.cuda.mem_get_info()[0] == free0, "the static call allocated device memory"
 r = b.records()
-for i, m in enumerate(meta[:24]):
+for i, m in enumerate(meta["streams"][:24]):
     assert (int(r["rc"][i]), int(r["got"][i]), int(r["used"][i])) == (0, m["got"], m["len"]), i
     assert int(r["check"][i]) == int(m["xxh64"], 16), i
 print("first-use ok")
