@@ -455,11 +455,15 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
        batches were better off in them too: 107 ms against 116 ms in full wavefronts at 131,072 streams) */
     /* with the write-behind form of the loop (YEAST_MERGE 2, below) full wavefronts win as soon as there is more than
        one round: 82.8 against 88.6 ms at 131,072 streams, 162.7 against 173.7 at 262,144 (one round: 49.3 against 47.6) */
-    const int merge = flat ? env_int("YEAST_MERGE", n >= (size_t)d.cus * 160 ? 2 : 0) : 0;
-    const int half = flat ? env_int("YEAST_HALF", merge == 2 && n > (size_t)d.cus * 256 ? 0 : 1) : 0;
+    /* YEAST_MERGE: the form of the batch kernel's loop.  3 (the default): write-behind through the LDS ring with the work of a
+       trip done per symbol kind (yeast_trip3.h): 41.3 ms at 8,192 streams, 43.0 at 32,768, 46.5 at 65,536 -- as fast as the
+       plain loop (0: 41.1 at 8,192) where a wavefront has its SIMD to itself and faster than the earlier write-behind
+       loop (2: 45.2 / 46.0 / 47.8) everywhere, so one form serves all batch sizes.  0, 1, 2 stay selectable (tests, A/B) */
+    const int merge = flat ? env_int("YEAST_MERGE", 3) : 0;
+    const int half = flat ? env_int("YEAST_HALF", merge >= 2 && n > (size_t)d.cus * 256 ? 0 : 1) : 0;
     unsigned per_block = 256u / (unsigned)lanes / (half == 2 ? 4u : half ? 2u : 1u);
     /* full wavefronts with the ring: 110 KB of LDS per block, one block per CU */
-    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : half == 0 && merge == 2 ? 1 : 2) : 4);
+    unsigned blocks_per_cu = (unsigned)env_int("YEAST_BLOCKS_PER_CU", flat ? (half == 2 ? 4 : half == 0 && merge >= 2 ? 1 : 2) : 4);
     size_t want_blocks = (n + per_block - 1) / per_block;
     size_t max_blocks = (size_t)d.cus * blocks_per_cu;
     unsigned blocks = (unsigned)(want_blocks < max_blocks ? want_blocks : max_blocks);
@@ -492,7 +496,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
            per command, 52.6 ms; 0: the plain loop, faster at 32,768 streams and fewer, where a wavefront has its SIMD to
            itself and every LDS round trip shows: 43.2 against 45.4 ms; the two meet at 40,960 streams) */
         {
-            int S = half == 2 ? 16 : half ? 32 : 64, form = (half == 0 || half == 1) && merge == 2 ? 2 : half == 1 && merge ? 1 : 0;
+            int S = half == 2 ? 16 : half ? 32 : 64, form = (half == 0 || half == 1) && merge >= 2 ? merge : half == 1 && merge ? 1 : 0;
             if (form)
                 snprintf(t_kernel, sizeof(t_kernel), "k_decode_lean<%d, %d>", S, form);
             else

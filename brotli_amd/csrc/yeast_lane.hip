@@ -174,6 +174,10 @@ static int launch_lean_t(const ys_params &p, u32 streams, hipStream_t st)
 /* streams = resident streams (each owns one workspace slot); half != 0: half-filled wavefronts */
 extern "C" int ysl_launch(const ys_params *p, int half, int merge, unsigned streams, void *stream)
 {
+    if (half == 1 && merge == 3)
+        return launch_lean_t<32, 3>(*p, streams, (hipStream_t)stream);
+    if (half == 0 && merge == 3)
+        return launch_lean_t<64, 3>(*p, streams, (hipStream_t)stream);
     if (half == 1 && merge == 2)
         return launch_lean_t<32, 2>(*p, streams, (hipStream_t)stream);
     if (half == 0 && merge == 2)

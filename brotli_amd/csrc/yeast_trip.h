@@ -788,6 +788,8 @@ NOINL TripOut run_trip_fn(TripIn a)
     return o;
 }
 
+#include "yeast_trip3.h"
+
 template <int SF>
 DEV void run_trip(Ctx &c, u32 &mlen, const FlatEnv &fe)
 {
@@ -818,7 +820,11 @@ DEV void run_trip(Ctx &c, u32 &mlen, const FlatEnv &fe)
 #ifdef YS_PROFILE
     a.t_start = c.t_start;
 #endif
-    TripOut o = run_trip_fn<SF>(a);
+    TripOut o;
+    if constexpr ((SF >> 8) == 3)
+        o = run_trip3_fn<(SF & 0xff)>(a);
+    else
+        o = run_trip_fn<SF>(a);
     c.outp = o.outp;
     c.r0 = o.r0; c.r1 = o.r1; c.r2 = o.r2; c.r3 = o.r3;
     mlen = o.mlen;

@@ -64,8 +64,8 @@ KERNELS = [64, 65, 1]  # cooperative, wavefront per stream (LDS tables), one str
 # (one stream per lane) in the three forms the dispatcher uses by batch size -- (YEAST_MERGE, YEAST_HALF) =
 # (0, 1) plain loop, half-filled wavefronts (small batches); (2, 1) write-behind through the LDS ring, half-filled
 # (one round: what bench.py runs at 65,536 streams); (2, 0) the same in full wavefronts (more than one round).
-FORMS = [64, 65, (1, 0, 1), (1, 2, 1), (1, 2, 0)]
-FORM_IDS = ["coop64", "wave", "lean-plain", "lean-ring-half", "lean-ring-full"]
+FORMS = [64, 65, (1, 0, 1), (1, 2, 1), (1, 2, 0), (1, 3, 1), (1, 3, 0)]
+FORM_IDS = ["coop64", "wave", "lean-plain", "lean-ring-half", "lean-ring-full", "lean-kinds-half", "lean-kinds-full"]
 
 
 def use_form(monkeypatch, form):
@@ -210,7 +210,7 @@ def test_randomly_assembled_streams(lanes, monkeypatch):
         assert r[1] == out, i
 
 
-@pytest.mark.parametrize("merge,half", [(1, 1), (2, 1), (2, 0)])
+@pytest.mark.parametrize("merge,half", [(1, 1), (2, 1), (2, 0), (3, 1), (3, 0)])
 def test_batch_kernel_with_one_store_per_command(monkeypatch, merge, half):
     # the forms of the batch kernel that gather the stores of the output (YEAST_MERGE 1: a copy's last piece and the
     # literals behind it stored as one unit, the form large batches get; 2: every byte through a ring in LDS and out in
@@ -332,7 +332,8 @@ def test_fuzzed_streams_same_error_class_and_progress(form, monkeypatch):
     assert {2, 3} <= classes
 
 
-@pytest.mark.parametrize("form", [(1, 0, 1), (1, 2, 1), (1, 2, 0), 65, 16], ids=["lean-plain", "lean-ring-half", "lean-ring-full", "wave", "coop16"])
+@pytest.mark.parametrize("form", [(1, 0, 1), (1, 2, 1), (1, 2, 0), (1, 3, 1), (1, 3, 0), 65, 16],
+                         ids=["lean-plain", "lean-ring-half", "lean-ring-full", "lean-kinds-half", "lean-kinds-full", "wave", "coop16"])
 def test_damage_deep_inside_full_length_streams(form, monkeypatch):
     # bit flips and cuts anywhere in whole 64 KiB streams: the failure (or the wrong but valid decode)
     # happens thousands of commands into the loop, beside healthy streams in the same wavefront
@@ -389,8 +390,8 @@ def test_full_size_batch_properties():
     assert (r["check"] == want).all()
 
 
-@pytest.mark.parametrize("half", [1, 0], ids=["ring-half", "ring-full"])
-def test_wavefronts_take_further_streams_when_theirs_are_done(half, monkeypatch):
+@pytest.mark.parametrize("merge,half", [(2, 1), (2, 0), (3, 1), (3, 0)], ids=["ring-half", "ring-full", "kinds-half", "kinds-full"])
+def test_wavefronts_take_further_streams_when_theirs_are_done(merge, half, monkeypatch):
     # The batch kernel holds 65,536 streams at a time (256 per CU); a wavefront whose streams are all done takes the
     # next S from the queue (yeast_lane.hip k_decode_lean's loop).  72,000 short streams -- random plans whole and
     # damaged, the crafted good and bad streams -- force that in both ring forms (S = 32 and S = 64); every record
@@ -399,7 +400,7 @@ def test_wavefronts_take_further_streams_when_theirs_are_done(half, monkeypatch)
     import random_plans as R
     import torch
     from brotli_amd.device import DeviceBatch
-    monkeypatch.setenv("YEAST_MERGE", "2")
+    monkeypatch.setenv("YEAST_MERGE", str(merge))
     monkeypatch.setenv("YEAST_HALF", str(half))
     ss = [s for s, _ in R.streams(240, 4242 + half)]
     rnd = random.Random(17 + half)
@@ -437,7 +438,7 @@ def test_wavefronts_take_further_streams_when_theirs_are_done(half, monkeypatch)
     batch.dst.fill_(0xEE)
     batch.decode(check=ba.CHECK_XXH64, lanes=1)
     torch.cuda.synchronize()
-    assert ba.lib().yeast_last_kernel() == (b"k_decode_lean<32, 2>" if half else b"k_decode_lean<64, 2>")
+    assert ba.lib().yeast_last_kernel() == b"k_decode_lean<%d, %d>" % (32 if half else 64, merge)
     r = batch.records()
     w_rc = np.array([want[j][0] for j in pick])
     w_got = np.array([want[j][1] for j in pick], dtype=np.uint64)
