@@ -329,7 +329,7 @@ static const char *const KNOB_NAMES[] = {"YEAST_LANES", "YEAST_WAVES_PER_CU", "Y
                                          "YEAST_ROOT_IAC", "YEAST_ROOT_DIST", "YEAST_HALF", "YEAST_BLOCKS_PER_CU",
                                          "YEAST_WS_KB", "YEAST_LEAN_ROOT_LIT", "YEAST_LEAN_ROOT_IAC",
                                          "YEAST_LEAN_ROOT_DIST", "YEAST_SORT", "YEAST_DEBUG", "YEAST_HOST_THREADS",
-                                         "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB", "YEAST_MERGE"};
+                                         "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB", "YEAST_MERGE", "YEAST_PAIR"};
 enum { KNOBS = sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]) };
 static int g_knob_val[KNOBS];
 static bool g_knob_set[KNOBS];
@@ -491,6 +491,9 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
             p.order = order;
         }
         p.debug = (u32)env_int("YEAST_DEBUG", 0);
+        /* two blocks per CU, all resident at once, sorted hand-out: pair long with short on a SIMD (yeast_lane.hip) */
+        if (p.order && blocks_per_cu == 2 && blocks == 2 * (unsigned)d.cus && (blocks & 1) == 0 && env_int("YEAST_PAIR", 1))
+            p.debug |= 2; /* (issue priority for the wavefronts with the long streams on top of it: no difference, 46.5 ms either way) */
         /* batches that fill the GPU: the loop that gathers its stores (yeast_trip.h; YEAST_MERGE 2: every output byte
            through a ring in LDS and out in complete 16-byte chunks, 47.6 ms against 57.4 at 65,536 streams; 1: one store
            per command, 52.6 ms; 0: the plain loop, faster at 32,768 streams and fewer, where a wavefront has its SIMD to

@@ -35,11 +35,25 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
     if (p.debug & 1) /* every stream of the wavefront uses one workspace: only meaningful when they are copies of one stream */
         ws = wbase;
     const u32 limit = p.retry ? *p.retry_count : p.n;
+    /* Pairing (p.debug bit 1; the host sets it when every block is resident at once, two per CU): the streams are handed
+       out longest first, and blocks b and b + gridDim.x / 2 land on the same CU (observed, not promised: it only decides
+       who shares a SIMD, never what is decoded).  The first half of the blocks takes the order as it is, the second half
+       takes it from the end, so the wavefront with the longest streams shares its SIMD with the one that has the shortest
+       and has it to itself soonest.  Later rounds, if any, take what is left in order. */
+    bool first = (p.debug & 2) != 0 && !p.retry;
+    const u32 nblk = gridDim.x;
     for (;;) {
         u32 base = 0;
-        if ((lane & 63) == 0)
-            base = atomicAdd(p.counter, (u32)S);
-        base = __builtin_amdgcn_readfirstlane(base);
+        if (first) {
+            const u32 b = blockIdx.x, half = nblk >> 1;
+            const u32 r = b < half ? b : nblk - 1 - (b - half);
+            base = (r * 4 + (lane >> 6)) * S;
+            first = false;
+        } else {
+            if ((lane & 63) == 0)
+                base = atomicAdd(p.counter, (u32)S) + ((p.debug & 2) && !p.retry ? nblk * 4 * S : 0);
+            base = __builtin_amdgcn_readfirstlane(base);
+        }
         if (base >= limit)
             break;
         u32 job = base + slot;

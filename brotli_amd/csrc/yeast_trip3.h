@@ -141,6 +141,7 @@ NOINL TripOut run_trip3_fn(TripIn a)
             ring_put8((0u - j) & 63, gld8(a.outp - j));
     }
 
+#define WAITV(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory") /* at most n of the trip's three loads in flight */
     u32 st = YT_CMD, cat = 0;
     u32 la = 0, lw = 0, lk = 0;
     u32 lo = 0, hi = 0;
@@ -207,15 +208,41 @@ NOINL TripOut run_trip3_fn(TripIn a)
             budget = v > budget ? v : budget;
         }
     }
+#ifdef YS_PROFILE
+    u32 ntrip = 0;
+    u64 pwait = 0, pwait2 = 0, pwait3 = 0, plast;
+    u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(plast)::"memory");
+    const u64 t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
     while (__any(st != YT_END)) {
         if (--budget == 0) {
             rc = st != YT_END && !rc ? (u32)YS_WORKSPACE : rc;
             break;
         }
         /* ================= 1. the entry arrives: the code, then what the symbol means ================= */
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#ifdef YS_PROFILE
+        ntrip++;
+        u64 ta_, tb_;
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta_)::"memory");
+#endif
+        WAITV(2);
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
+        pwait += tb_ - ta_;
+#endif
         u32 en = wl->ent[slot];
         asm volatile("" : "+v"(en));
+        TMARK(0);
+#ifdef YT3_PAD_A /* measurement build: what an instruction costs at this place (dependent vector adds) */
+        {
+            u32 padv = st;
+#pragma unroll
+            for (int i = 0; i < YT3_PAD_A; i++)
+                asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv));
+            asm volatile("" ::"v"(padv));
+        }
+#endif
         const u32 l = en & 15, sym = (en >> 4) & 0xfff;
         const bool active = st <= YT_BC;
         /* a code longer than the table's index: the entry names the second table (lk != 0 there, and no code of
@@ -330,8 +357,16 @@ NOINL TripOut run_trip3_fn(TripIn a)
             }
         }
 
+        TMARK(1);
         /* ================= 2. the other two loads of the last trip: input words, the copy's piece ================= */
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta_)::"memory");
+#endif
+        WAITV(1);
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
+        pwait2 += tb_ - ta_;
+#endif
         {
             const bool got4 = treq != 0;
             const u32x4 tv = wl->top[slot];
@@ -351,7 +386,15 @@ NOINL TripOut run_trip3_fn(TripIn a)
         if (st == YT_HOLD)
             nk = crem != m ? YT_NONE : mlen == 0 ? YT_END : YT_CMD;
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TMARK(2);
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ta_)::"memory");
+#endif
+        WAITV(0);
+#ifdef YS_PROFILE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
+        pwait3 += tb_ - ta_;
+#endif
         const u32 ac = (u32)(uintptr_t)op - base_lo; /* bytes produced by this call */
         if (pn) { /* the piece asked for on the last trip: sixteen bytes whatever pn, the excess lies where the next bytes go */
             const LAS u8 *pb = po ? (const LAS u8 *)(rb + (po - 1)) : (const LAS u8 *)&wl->piece[slot];
@@ -368,6 +411,7 @@ NOINL TripOut run_trip3_fn(TripIn a)
             wn -= 16;
         }
 
+        TMARK(3);
         /* ================= 3. what comes next, and the request for it ================= */
         {
             /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
@@ -381,7 +425,18 @@ NOINL TripOut run_trip3_fn(TripIn a)
             enter(nk <= YT_GO, w, w == YT_CMD ? offI : wso + o, left0, left1, left2);
         }
         st = nk == YT_END ? YT_END : st;
+        TMARK(4);
         request(st <= YT_BC && (nk <= YT_GO || is_link || btc));
+        TMARK(5);
+#ifdef YT3_PAD_C /* measurement build: what an instruction costs at this place (dependent vector adds) */
+        {
+            u32 padv = st;
+#pragma unroll
+            for (int i = 0; i < YT3_PAD_C; i++)
+                asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv));
+            asm volatile("" ::"v"(padv));
+        }
+#endif
 
         /* ================= 4. under those loads: the copy that begins, the next piece ================= */
         if (nk == YT_GO) {
@@ -442,6 +497,7 @@ NOINL TripOut run_trip3_fn(TripIn a)
             /* the meta-block ends with this copy (:1295): the entry asked for above is never looked at */
             st = mlen == 0 ? YT_END : st;
         }
+        TMARK(6);
         /* the next piece of the copy: requested now, appended to the ring on the next trip */
         {
             const bool piece = crem != 0;
@@ -458,8 +514,32 @@ NOINL TripOut run_trip3_fn(TripIn a)
             /* more pieces to come: the stream stands still meanwhile (and the meta-block may end with the copy) */
             st = crem != 0 ? YT_HOLD : st;
         }
+#ifdef YT3_PAD_B /* measurement build: what an instruction costs at this place (dependent vector adds) */
+        {
+            u32 padv = st;
+#pragma unroll
+            for (int i = 0; i < YT3_PAD_B; i++)
+                asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv));
+            asm volatile("" ::"v"(padv));
+        }
+#endif
+        TMARK(7);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef YS_PROFILE
+    if ((threadIdx.x & 63) == 0 && a.cap >= 128) { /* the profile build's output bytes are not meant to be looked at */
+        u64 *prof = (u64 *)(a.out + a.cap - 128);
+        prof[12] = ntrip;
+        prof[2] = pwait;
+        prof[3] = pwait2;
+        prof[4] = pwait3;
+        for (int i = 0; i < 7; i++)
+            prof[5 + i] = pt[i];
+        prof[15] = pt[7];
+        prof[13] = t_loop - a.t_start;
+        prof[14] = __builtin_amdgcn_s_memrealtime() - t_loop;
+    }
+#endif
     { /* the piece set up last, then what the ring still holds, byte by byte */
         if (pn) {
             const LAS u8 *pb = po ? (const LAS u8 *)(rb + (po - 1)) : (const LAS u8 *)&wl->piece[slot];
