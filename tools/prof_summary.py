@@ -15,24 +15,25 @@ for f in sorted(glob.glob(os.path.join(base, "**", "*counter_collection.csv"), r
     for k, v in agg.items():
         print(k, {a: b for a, b in v.items()})
 
-# HBM traffic of the dominant kernel per launch, for bench.py's roofline.traffic, as MI355X_MICROARCH.md
-# (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE from separate --pmc passes, KiB x 1024, and on
-# gfx950 FETCH_SIZE doubled (it tallies 128-byte requests at 64 bytes).  The guide calibrated the factor
-# on wide streaming reads; this kernel's reads are scattered, so the doubled figure is an upper bound
-# and the raw one is kept beside it.
-import json
-tot = {}
+# HBM traffic of the dominant kernel per launch, for bench.py's roofline.traffic, as MI355X_MICROARCH.md (HBM section)
+# prescribes: FETCH_SIZE and WRITE_SIZE from separate --pmc passes, KiB x 1024.  The guide's gfx950 correction (FETCH_SIZE
+# reports half the bytes) is for wide streaming reads; it says to calibrate other patterns.  tools/ubench/fetch_calib.hip
+# (profiles/r03/fetch_calibration.txt) did: scattered 2-byte and 16-byte loads, one per 64-byte line -- this kernel's table
+# lookups and copy pieces -- are counted exactly (x 1.000, one 64-byte fetch per L2 miss), the streaming read x 0.5.  So
+# the factor here is 1, and the x 2 figure is kept beside it as the upper bound round 2 quoted.
+import json, re
+tot, kname = {}, None
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(os.path.join(base, "**", "*counter_collection.csv"), recursive=True):
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if r["Counter_Name"] == name and "k_decode_lean" in r["Kernel_Name"]]
-        if vals:
-            tot[name] = sum(vals) / len(vals) * 1024.0
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name and "k_decode_lean" in r["Kernel_Name"]]
+        if rows:
+            tot[name] = sum(float(r["Counter_Value"]) for r in rows) / len(rows) * 1024.0
+            kname = re.sub(r"^void |\(.*$", "", rows[0]["Kernel_Name"])
 if len(tot) == 2 and len(sys.argv) > 2:
-    out = {"streams": int(sys.argv[2]), "kernel": "k_decode_lean<32, 2>", "fetch_bytes": tot["FETCH_SIZE"],
-           "fetch_bytes_gfx950_corrected": 2 * tot["FETCH_SIZE"],
-           "write_bytes": tot["WRITE_SIZE"], "bytes_per_launch": 2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"],
-           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB x 1024, FETCH_SIZE x 2 "
-                     "(gfx950), mean over launches"}
+    out = {"streams": int(sys.argv[2]), "kernel": kname, "fetch_bytes": tot["FETCH_SIZE"], "fetch_factor": 1.0,
+           "fetch_bytes_if_streaming_x2": 2 * tot["FETCH_SIZE"],
+           "write_bytes": tot["WRITE_SIZE"], "bytes_per_launch": tot["FETCH_SIZE"] + tot["WRITE_SIZE"],
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB x 1024, mean over launches; FETCH_SIZE x 1: "
+                     "calibrated on scattered 2- and 16-byte loads (profiles/r03/fetch_calibration.txt)"}
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "hbm_traffic.json"), "w"), indent=1)
     print("hbm_traffic.json:", out)
