@@ -138,10 +138,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    rehearsal = bool(os.environ.get("BENCH_TEST_BACKEND")) and world > 1
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # BENCH_TEST_BACKEND=gloo: a rehearsal of the N > 1 code path on a box with ONE GPU (every rank on device 0, the
+        # records gathered through gloo); never a measurement
+        test_backend = os.environ.get("BENCH_TEST_BACKEND")
+        if test_backend:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(test_backend)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -186,7 +195,7 @@ def main():
         def step():
             batch.decode(check=args.check, lanes=args.lanes)
             if dist is not None:
-                return all_gather_records(batch.rec, dist, sizes=sizes)
+                return all_gather_records(batch.rec.cpu() if rehearsal else batch.rec, dist, sizes=sizes)
             return batch.rec
         for _ in range(args.warmup):
             step()
@@ -212,7 +221,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -274,7 +283,7 @@ def main():
         "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "verified": verified[0],
-        "dtype": "u8", "data": "synthetic",
+        "dtype": "u8", "data": "synthetic" if not os.environ.get("BENCH_TEST_BACKEND") else "REHEARSAL: all ranks on one GPU, not a measurement",
         "config": {"workload": "cfg2: %s x 65,536 B out, q11 lgwin22 English text, %d distinct "
                                "streams tiled in seeded order; decode + %s check%s"
                                % ("%d streams in all, sharded by compressed bytes over %d GPU(s)" % (args.streams, world)
