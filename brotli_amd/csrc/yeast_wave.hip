@@ -602,6 +602,19 @@ DEV void w_raw(WCtx &c, const u8 *from, u32 n)
     c.p1 = RFL(gld8(from + n - 1));
 }
 
+/* The command loop out of line: as a function of its own it has the scalar registers to itself (inlined into the
+   kernel, the stream's whole state competed for them and the loop ran on spilled registers: 648 v_readlane, 225
+   v_writelane and 234 scratch accesses in the kernel's code).  State goes in and comes back by value. */
+struct WCmdIO {
+    WCtx c;
+    u32 mlen;
+};
+NOINL WCmdIO w_commands_fn(WCmdIO io, WEnv env, WConst K)
+{
+    w_commands(io.c, io.mlen, env, K);
+    return io;
+}
+
 /* metablock(): yeast.c:971-1308.  Returns ISLAST. */
 DEV u32 w_metablock(WCtx &c, const WConst &K)
 {
@@ -746,7 +759,15 @@ DEV u32 w_metablock(WCtx &c, const WConst &K)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     WMARK(0);
-    w_commands(c, mlen, env, K);
+    {
+        WCmdIO io;
+        io.c = c;
+        io.mlen = mlen;
+        io = w_commands_fn(io, env, K);
+        c = io.c;
+        mlen = io.mlen;
+        wctx_uniform(c);
+    }
     WMARK(5);
 
     if (!r.rc && last && tail_nonzero(r))
