@@ -154,15 +154,16 @@ DEV u32 crc_word(const u32 *tab, u32 crc, u32 w)
 /* each lane takes a contiguous slice (a multiple of 16 bytes, read 16 bytes at a time), then the
    slices are combined with the zeros operator (crc32c_zeros_op/crc32c_shift, crc32c.c:82-134) in
    its polynomial form */
-DEV u32 wave_crc32c(const u32 *tab /*LDS, 4 x 256*/, const u8 *p, u64 len, u32 init, u32 lane)
+template <u32 SLICES>
+DEV u32 slice_crc32c(const u32 *tab /*LDS, 4 x 256*/, const u8 *p, u64 len, u32 init, u32 slice)
 {
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     typedef u32x4 __attribute__((aligned(1))) u32x4u;
-    u64 per = (((len + 63) >> 6) + 15) & ~15ull;
-    u64 a = per * lane, e = a + per;
+    u64 per = (((len + SLICES - 1) / SLICES) + 15) & ~15ull;
+    u64 a = per * slice, e = a + per;
     if (a > len) a = len;
     if (e > len) e = len;
-    u32 crc = lane == 0 ? ~init : 0xffffffffu;
+    u32 crc = slice == 0 ? ~init : 0xffffffffu;
     u64 i = a;
     for (; i + 32 <= e; i += 32) {
         u32x4 x = *(const GAS u32x4u *)(p + i), y = *(const GAS u32x4u *)(p + i + 16);
@@ -178,12 +179,37 @@ DEV u32 wave_crc32c(const u32 *tab /*LDS, 4 x 256*/, const u8 *p, u64 len, u32 i
     for (; i < e; i++)
         crc = tab[(crc ^ ld8(p + i)) & 255] ^ (crc >> 8);
     crc = ~crc;
-    /* shift by the bytes that follow this slice and fold */
-    u32 part = crc_mul(crc_x8n(len - e), crc);
+    /* shift by the bytes that follow this slice; the CRC of the whole is the XOR of these over the slices */
+    return a == e && slice ? 0 : crc_mul(crc_x8n(len - e), crc);
+}
+
+DEV u32 wave_xor(u32 part)
+{
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         part ^= __shfl_xor(part, o);
     return part;
+}
+
+DEV u32 wave_crc32c(const u32 *tab, const u8 *p, u64 len, u32 init, u32 lane)
+{
+    return wave_xor(slice_crc32c<64>(tab, p, len, init, lane));
+}
+
+/* CRC-32C of one buffer by a whole block of 1,024 lanes: as many slices, folded through LDS (a single wavefront
+   reads 3.7 GB/s: 4.6 ms for the 18 MB output of BASELINE config 5) */
+DEV u32 block_crc32c(const u32 *tab, u32 *fold /*LDS, 16*/, const u8 *p, u64 len, u32 init)
+{
+    u32 part = wave_xor(slice_crc32c<1024>(tab, p, len, init, threadIdx.x));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        fold[threadIdx.x >> 6] = part;
+    __syncthreads();
+    u32 v = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        v ^= fold[k];
+    return v;
 }
 
 DEV void crc_tables(u32 *tab /*LDS, 4 x 256*/)
@@ -234,20 +260,40 @@ __global__ __launch_bounds__(256) void k_check(const u8 *dst, const u64 *dst_off
     }
 }
 
-/* plain buffers: one wave per (ptr,len) pair */
-__global__ __launch_bounds__(64) void k_check_buf(const u8 *p, u64 len, u32 kind, u64 seed, u64 *out)
+/* CRC-32C over few streams: one block of sixteen wavefronts per stream */
+__global__ __launch_bounds__(1024) void k_crc_wide(const u8 *dst, const u64 *dst_off, ys_record *rec, u32 n, u32 init,
+                                                   int only_ok)
 {
     __shared__ u32 s_tab[1024];
+    __shared__ u32 s_fold[16];
+    crc_tables(s_tab);
+    for (u32 j = blockIdx.x; j < n; j += gridDim.x) {
+        ys_record r = rec[j];
+        if (only_ok && r.rc != YS_OK && r.rc != YS_MISMATCH && r.rc != YS_EOF && r.rc != YS_INVALID)
+            continue; /* the same for the whole block */
+        u32 v = block_crc32c(s_tab, s_fold, dst + dst_off[j], r.got, init);
+        if (threadIdx.x == 0)
+            rec[j].check = v;
+    }
+}
+
+/* plain buffers: one wave per (ptr,len) pair (CRC-32C of a long one: sixteen) */
+__global__ __launch_bounds__(1024) void k_check_buf(const u8 *p, u64 len, u32 kind, u64 seed, u64 *out)
+{
+    __shared__ u32 s_tab[1024];
+    __shared__ u32 s_fold[16];
     crc_tables(s_tab);
     u32 lane = threadIdx.x & 63;
     u64 v;
-    if (kind == 1)
+    if (blockDim.x == 1024) /* CRC-32C only */
+        v = block_crc32c(s_tab, s_fold, p, len, (u32)seed);
+    else if (kind == 1)
         v = wave_crc32c(s_tab, p, len, (u32)seed, lane);
     else if (kind == 2)
         v = quad_xxh32(p, len, (u32)seed, lane & 3);
     else
         v = quad_xxh64(p, len, seed, lane & 3);
-    if (lane == 0)
+    if (threadIdx.x == 0)
         *out = v;
 }
 
@@ -262,6 +308,10 @@ extern "C" int ys_launch_check(const u8 *dst, const u64 *dst_off, ys_record *rec
                                u64 seed, void *stream)
 {
     if (n == 0) return 0;
+    if (kind == 1 && n <= 2048) { /* few streams: the wavefronts that would idle share each stream */
+        hipLaunchKernelGGL(k_crc_wide, dim3(n), dim3(1024), 0, (hipStream_t)stream, dst, dst_off, rec, n, (u32)seed, 1);
+        return (int)hipGetLastError();
+    }
     u64 per_block = kind == 1 ? 4 : 64; /* streams a block of 256 lanes takes at a time */
     u64 want = (n + per_block - 1) / per_block;
     u32 blocks = (u32)(want < 256 * 8 ? want : 256 * 8);
@@ -281,7 +331,8 @@ extern "C" int ys_warm_check(void *stream)
 
 extern "C" int ys_launch_check_buf(const u8 *p, u64 len, unsigned kind, u64 seed, u64 *out, void *stream)
 {
-    hipLaunchKernelGGL(k_check_buf, dim3(1), dim3(64), 0, (hipStream_t)stream, p, len, kind, seed, out);
+    hipLaunchKernelGGL(k_check_buf, dim3(1), dim3(kind == 1 && len >= 65536 ? 1024 : 64), 0, (hipStream_t)stream, p, len,
+                       kind, seed, out);
     return (int)hipGetLastError();
 }
 

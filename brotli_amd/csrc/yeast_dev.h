@@ -59,6 +59,63 @@ DEV void gst64u(void *p, u64 v)
     *(GAS u64u *)p = v;
 }
 
+/* A long copy by a whole wavefront (64 lanes): n bytes from d bytes back, d >= n or d >= 1024.  Byte-serial semantics
+   (yeast.c:1285-1293) hold as long as a byte is read after it was written, so the copy goes in segments no longer than d
+   (a whole segment's source lies behind its destination) with a wait for the stores between segments; inside a
+   segment the order is free: 16-byte units, YS_COPY_U loads in flight per lane before the first store (one load and
+   its dependent store at a time is one memory round trip per 512 bytes: 28 ms for the 18 MB of BASELINE config 5).
+   Out of line: the unit buffer is registers the caller's loop should not be allocated around. */
+#ifndef YS_COPY_U
+#define YS_COPY_U 16
+#endif
+static NOINL void wave_copy_units(u8 *t, const u8 *s, u32 units, u32 lane)
+{
+    for (u32 k0 = lane; k0 < units; k0 += 64 * YS_COPY_U) {
+        u32x4 v[YS_COPY_U];
+        if (k0 + 64 * (YS_COPY_U - 1) < units) { /* a full batch for this lane */
+#pragma unroll
+            for (u32 u = 0; u < YS_COPY_U; u++)
+                v[u] = gld128u(s + 16 * (size_t)(k0 + u * 64));
+#pragma unroll
+            for (u32 u = 0; u < YS_COPY_U; u++)
+                gst128u(t + 16 * (size_t)(k0 + u * 64), v[u]);
+        } else {
+#pragma unroll
+            for (u32 u = 0; u < YS_COPY_U; u++)
+                if (k0 + u * 64 < units)
+                    v[u] = gld128u(s + 16 * (size_t)(k0 + u * 64));
+#pragma unroll
+            for (u32 u = 0; u < YS_COPY_U; u++)
+                if (k0 + u * 64 < units)
+                    gst128u(t + 16 * (size_t)(k0 + u * 64), v[u]);
+        }
+    }
+}
+
+/* n bytes that do not overlap their source (a stored block: yeast.c:1061-1070) */
+DEV void wave_copy_disjoint(u8 *t, const u8 *s, u32 n, u32 lane)
+{
+    const u32 units = n >> 4;
+    wave_copy_units(t, s, units, lane);
+    const u32 t0 = units << 4;
+    if (lane < (n & 15))
+        gst8(t + t0 + lane, gld8(s + t0 + lane));
+}
+
+DEV void wave_copy_far(u8 *dst, u32 d, u32 n, u32 lane)
+{
+    const u8 *from = dst - d;
+    u32 done = 0;
+    while (done < n) {
+        u32 seg = n - done;
+        if (seg > d)
+            seg = d & ~15u;
+        wave_copy_disjoint(dst + done, from + done, seg, lane);
+        done += seg;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the next segment reads what this one wrote */
+    }
+}
+
 /* ------------------------------------------------------------- bit reader */
 
 struct Rd {

@@ -329,7 +329,8 @@ static const char *const KNOB_NAMES[] = {"YEAST_LANES", "YEAST_WAVES_PER_CU", "Y
                                          "YEAST_ROOT_IAC", "YEAST_ROOT_DIST", "YEAST_HALF", "YEAST_BLOCKS_PER_CU",
                                          "YEAST_WS_KB", "YEAST_LEAN_ROOT_LIT", "YEAST_LEAN_ROOT_IAC",
                                          "YEAST_LEAN_ROOT_DIST", "YEAST_SORT", "YEAST_DEBUG", "YEAST_HOST_THREADS",
-                                         "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB", "YEAST_MERGE", "YEAST_PAIR"};
+                                         "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB", "YEAST_MERGE", "YEAST_PAIR",
+                                         "YEAST_HOST_FLOOR", "YEAST_D2H_PIN_KB"};
 enum { KNOBS = sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]) };
 static int g_knob_val[KNOBS];
 static bool g_knob_set[KNOBS];
@@ -713,6 +714,33 @@ template <class F> static void host_parallel(size_t n, u64 bytes, F fn)
         x.join();
 }
 
+/* one large memcpy shared by the same threads (pieces of whole pages) */
+static void host_parallel_bytes(u8 *to, const u8 *from, size_t n)
+{
+    unsigned t = (unsigned)env_int("YEAST_HOST_THREADS", 8), hw = std::thread::hardware_concurrency();
+    if (hw && t > hw)
+        t = hw;
+    if (n < ((size_t)2 << 20) || t < 2) {
+        memcpy(to, from, n);
+        return;
+    }
+    size_t piece = round_up((n + t - 1) / t, 4096);
+    std::vector<std::thread> th;
+    size_t at = piece; /* this thread takes the first piece */
+    try {
+        for (; at < n; at += piece) {
+            size_t k = n - at < piece ? n - at : piece;
+            th.emplace_back([=] { memcpy(to + at, from + at, k); });
+        }
+    } catch (...) {
+        if (at < n)
+            memcpy(to + at, from + at, n - at);
+    }
+    memcpy(to, from, piece < n ? piece : n);
+    for (std::thread &x : th)
+        x.join();
+}
+
 /* Decode n host streams; fills rec[] and, for cmp == 0, out[i] (malloc'd).
    expected/have: compare mode inputs (cmp != 0, n == 1 in practice). */
 static int run_host_batch_impl(size_t n, void const *const *src, const size_t *len, std::vector<ys_record> &rec,
@@ -787,6 +815,18 @@ static int run_host_batch_impl(size_t n, void const *const *src, const size_t *l
                 budget = (u64)64 << 20;
             if (env_int("YEAST_HOST_BUDGET_MB", 0) > 0) /* for the tests */
                 budget = (u64)env_int("YEAST_HOST_BUDGET_MB", 0) << 20;
+            /* a few streams: each gets a generous region whatever its header says (a stream of many meta-blocks,
+               or one that copies itself up from a small start, otherwise comes back for pass after pass, each
+               decoding from the beginning; address space in HBM costs nothing until it is written) */
+            if (m < 64) {
+                u64 fl = ((u64)256 << 20) / m, b2 = budget / (2 * m);
+                fl = fl > ((u64)32 << 20) ? (u64)32 << 20 : fl;
+                fl = (fl > b2 ? b2 : fl) & ~(u64)15;
+                if (env_int("YEAST_HOST_FLOOR", 1))
+                    for (size_t k = 0; k < m; k++)
+                        if (cap[todo[k]] < fl)
+                            cap[todo[k]] = fl;
+            }
             u64 sum = 0;
             size_t take = 0;
             std::vector<size_t> now;
@@ -884,7 +924,16 @@ static int run_host_batch_impl(size_t n, void const *const *src, const size_t *l
                 out[i] = malloc(r[k].got);
                 if (!out[i])
                     return 1;
-                HIPCK(hipMemcpyAsync(out[i], (u8 *)d.dst.p + doff[k], r[k].got, hipMemcpyDeviceToHost, st));
+                const u64 big = (u64)env_int("YEAST_D2H_PIN_KB", 1024) << 10;
+                if (big && r[k].got >= big && grow_pinned(d.pin, r[k].got) == 0) {
+                    /* a large output: over the link into pinned memory at the link's rate, then into the caller's
+                       fresh pages by several threads (a copy straight into pageable memory has the runtime pin
+                       those pages first, one fault after the other) */
+                    HIPCK(hipMemcpyAsync(d.pin.p, (u8 *)d.dst.p + doff[k], r[k].got, hipMemcpyDeviceToHost, st));
+                    HIPCK(hipStreamSynchronize(st));
+                    host_parallel_bytes((u8 *)out[i], (const u8 *)d.pin.p, r[k].got);
+                } else
+                    HIPCK(hipMemcpyAsync(out[i], (u8 *)d.dst.p + doff[k], r[k].got, hipMemcpyDeviceToHost, st));
             }
         }
         if (bulk) { /* one malloc'd buffer per stream, as the single call returns it */

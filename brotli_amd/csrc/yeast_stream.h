@@ -170,7 +170,13 @@ DEV void emit_copy(Ctx &c, u32 n, u32 d, u32 sub, bool ctx)
         }
         return;
     }
-    if (d >= n || (G == 1 && d >= 8)) {
+    if (G == 64 && n >= 1024 && (d >= n || d >= 1024)) { /* a long copy by the whole wavefront */
+        if (ctx) {
+            c.p1 = gld8(from + (n - 1) % d);
+            c.p2 = gld8(from + (n - 2) % d);
+        }
+        wave_copy_far(dst, d, n, sub);
+    } else if (d >= n || (G == 1 && d >= 8)) {
         /* disjoint (or, for a single lane, far enough apart to go in order):
            8-byte units spread over the lanes, then the tail */
         u32 i1 = n - 1, i2 = n - 2;
@@ -339,7 +345,9 @@ template <int G>
 DEV void copy_exact(u8 *dst, u32 n, u32 d, u32 sub)
 {
     const u8 *from = dst - d;
-    if (d >= n || (G == 1 && d >= 8)) {
+    if (G == 64 && n >= 1024 && (d >= n || d >= 1024)) { /* a long copy by the whole wavefront */
+        wave_copy_far(dst, d, n, sub);
+    } else if (d >= n || (G == 1 && d >= 8)) {
         if (n >= 8) {
             for (u32 j = sub * 8; j + 8 <= n; j += G * 8)
                 gst64u(dst + j, gld64u(from + j));
@@ -478,6 +486,8 @@ DEV void emit_raw(Ctx &c, const u8 *from, u32 n, u32 sub)
             rd_fail(c.r, YS_MISMATCH); /* memcmp over the block: got unchanged :1063 */
             return;
         }
+    } else if (G == 64 && n >= 1024) {
+        wave_copy_disjoint(dst, from, n, sub);
     } else {
         u32 n8 = n >> 3;
         for (u32 j = sub; j < n8; j += G)

@@ -544,12 +544,8 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
                 pdst = dst;
                 pn = n;
             } else {
-                if (d >= n) {
-                    for (u32 j = lane * 8; j + 8 <= n; j += 512)
-                        gst64u(dst + j, gld64u(from + j));
-                    u32 t0 = n & ~7u;
-                    if (lane < (n & 7))
-                        gst8(dst + t0 + lane, gld8(from + t0 + lane));
+                if (d >= n || d >= 1024) {
+                    wave_copy_far(dst, d, n, lane);
                 } else if (d >= 64) {
                     /* each 64-byte piece lies wholly behind its source; pieces go in order */
                     for (u32 j = 0; j < n; j += 64) {
@@ -592,11 +588,15 @@ DEV void w_raw(WCtx &c, const u8 *from, u32 n)
 {
     u8 *dst = c.outp;
     u32 lane = c.lane;
-    u32 n8 = n >> 3;
-    for (u32 j = lane; j < n8; j += 64)
-        gst64u(dst + 8 * j, gld64u(from + 8 * j));
-    for (u32 i = (n8 << 3) + lane; i < n; i += 64)
-        gst8(dst + i, gld8(from + i));
+    if (n >= 1024)
+        wave_copy_disjoint(dst, from, n, lane);
+    else {
+        u32 n8 = n >> 3;
+        for (u32 j = lane; j < n8; j += 64)
+            gst64u(dst + 8 * j, gld64u(from + 8 * j));
+        for (u32 i = (n8 << 3) + lane; i < n; i += 64)
+            gst8(dst + i, gld8(from + i));
+    }
     c.outp += n;
     c.p2 = n >= 2 ? RFL(gld8(from + n - 2)) : c.p1;
     c.p1 = RFL(gld8(from + n - 1));

@@ -308,6 +308,28 @@ def test_check_values_known_answers():
     assert ba.xxh32(alice[:777], 12345) == o.oracle_xxh32(alice[:777], 777, 12345)
 
 
+def test_crc32c_of_long_buffers_and_of_few_streams():
+    # a CRC-32C over one long buffer, or over a batch of few streams, is cut into 1,024 slices by a block of sixteen
+    # wavefronts (64 slices by one wavefront otherwise): lengths around the slice and block boundaries, chained too
+    o = H.oracle()
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, 5_000_001, dtype=np.uint8).tobytes()
+    for n in (0, 1, 15, 16, 17, 1023, 1024, 16383, 16384, 16385, 65535, 65536, 65537, 65536 + 16 * 1024,
+              (1 << 20) + 13, 5_000_001):
+        assert ba.crc32c(data[:n]) == o.oracle_crc32c(0, data[:n], n), n
+        assert ba.crc32c(data[:n], 0xdeadbeef) == o.oracle_crc32c(0xdeadbeef, data[:n], n), n
+    # device-resident records of three streams (one of them empty): the block kernel
+    from brotli_amd.device import DeviceBatch
+    m5, s5 = H.packed_streams("cfg5_streams")
+    streams = [s5[1], bytes.fromhex("06"), next(iter(H.testdata_pairs()))[1]]
+    want = [H.oracle_yeast(x) for x in streams]
+    b = DeviceBatch(streams, [max(w[1], 16) for w in want])
+    b.decode(check=ba.CHECK_CRC32C)
+    for r, w in zip(b.records(), want):
+        assert (r["rc"], r["got"]) == (w[0], w[1])
+        assert r["check"] == o.oracle_crc32c(0, w[3], len(w[3]))
+
+
 @pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
 def test_fuzzed_streams_same_error_class_and_progress(form, monkeypatch):
     # truncations and bit flips of real streams: rc, got, used and the partial output must agree

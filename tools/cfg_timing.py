@@ -19,8 +19,8 @@ res["cfg4"] = {"streams": len(streams), "out_bytes": out_bytes, "gpu_ms": tg * 1
 meta, streams = H.packed_streams("cfg5_streams")
 res["cfg5"] = []
 for m, s in zip(meta["streams"], streams):
-    ba.yeast_batch([s])
-    t0 = time.perf_counter(); (rc, out, got, used, chk), = ba.yeast_batch([s], ba.CHECK_CRC32C); tg = time.perf_counter() - t0
+    ba.yeast_batch([s])  # the CPU beside it computes no check either
+    t0 = time.perf_counter(); (rc, out, got, used, chk), = ba.yeast_batch([s]); tg = time.perf_counter() - t0
     t0 = time.perf_counter(); c = cpu(s); tc = time.perf_counter() - t0
     assert rc == m["rc"] and got == m["got"]
     res["cfg5"].append({"name": m["name"], "out_bytes": got, "gpu_ms": tg * 1e3, "cpu_1core_ms": tc * 1e3})
