@@ -407,7 +407,12 @@ NOINL TripOut run_trip3_fn(TripIn a)
         }
         if (wn >= 16) { /* at most 15 + 16 before: one chunk a trip keeps up */
             const u32 co = (ac - wn) & 63; /* a multiple of 16 */
+#ifdef YT3_NT_STORE /* measurement aid: the output's lines are not kept in L2 */
+            typedef u32x4 __attribute__((aligned(16))) u32x4al;
+            __builtin_nontemporal_store(*(const LAS u32x4u *)(rb + co), (GAS u32x4al *)(op - wn));
+#else
             gst128u(op - wn, *(const LAS u32x4u *)(rb + co));
+#endif
             wn -= 16;
         }
 

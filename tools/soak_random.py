@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""One-off soak: many randomly assembled streams (tests/random_plans.py, several seeds) through the batch kernel and
-(both forms) and the wavefront-per-stream kernel against the CPU restatement.
+"""One-off soak: many randomly assembled streams (tests/random_plans.py, several seeds) through the batch kernel
+(every loop form, half-filled and full wavefronts), the wavefront-per-stream kernel and the cooperative kernel against
+the CPU restatement.
 usage: tools/soak_random.py [seeds] [streams per seed] [damaged: 0|1] [first seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +29,7 @@ for seed in range(first, first + seeds):
             extra.append((bytes(b), None))
         ss = ss + extra
     want = [H.oracle_yeast(s) for s, _ in ss]
-    for lanes, merge, half in ((1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 2, 0), (65, 0, 1)):
+    for lanes, merge, half in ((1, 3, 1), (1, 3, 0), (1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 2, 0), (65, 3, 1), (64, 3, 1)):
         os.environ["YEAST_FORCE_LANES"] = str(lanes)
         os.environ["YEAST_MERGE"] = str(merge)
         os.environ["YEAST_HALF"] = str(half)
