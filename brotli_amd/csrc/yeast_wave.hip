@@ -347,7 +347,17 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
         pk = 0;
     };
 
-    u32 cur_mode = RFL(gld8(env.mode + c.L.type));
+    /* context_id() (yeast.c:698-755) of the current literal block type as two byte tables, four entries per lane:
+       id = A[p1] | B[p2] whatever the mode (LSB6: A = b & 63; MSB6: A = b >> 2; UTF8: lut0, lut1; signed: lut2 << 3, lut2) */
+    u32 cxa = 0, cxb = 0;
+    auto set_mode = [&]() {
+        const u32 mode = RFL(gld8(env.mode + c.L.type));
+        const u32 b = lane * 4;
+        const u32 m0 = (b & 63) | (((b + 1) & 63) << 8) | (((b + 2) & 63) << 16) | (((b + 3) & 63) << 24);
+        cxa = mode == 0 ? m0 : mode == 1 ? lane * 0x01010101u : mode == 2 ? K.l0 : K.l2 << 3;
+        cxb = mode == 2 ? K.l1 : mode == 3 ? K.l2 : 0u;
+    };
+    set_mode();
     u32 descI = c.I.num > 1 ? RFL(itab[c.I.type]) : RFL(itab[0]);
     u32 ltv = ctx ? ltab[(c.L.type << 6) + lane] : 0; /* literal table of each context of this block type */
     u32 litv = 0;
@@ -374,8 +384,8 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
         u32 icode = ((u32)(INS_CELL >> (5 * cell)) & 31) + ((cmd >> 3) & 7);
         u32 ccode = ((u32)(CPY_CELL >> (5 * cell)) & 31) + (cmd & 7);
         u32 ie = rdlane(K.cmd, icode), ce = rdlane(K.cmd, 32 + ccode);
-        u32 insert = (ie & 0xffff) + wtake(ie >> 16);
-        u32 copy = (ce & 0xffff) + wtake(ce >> 16);
+        u32 insert = uni((ie & 0xffff) + wtake(ie >> 16));
+        u32 copy = uni((ce & 0xffff) + wtake(ce >> 16));
         if (r.rc)
             break;
         if (insert > mlen) {
@@ -394,25 +404,15 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
                 if (c.L.num > 1) {
                     if (c.L.left == 0) {
                         wswitch(c.L);
-                        cur_mode = RFL(gld8(env.mode + c.L.type));
+                        set_mode();
                         if (ctx)
                             ltv = ltab[(c.L.type << 6) + lane];
                     }
                     c.L.left--;
                 }
                 u32 desc = env.descL0;
-                if (ctx) { /* context_id(): yeast.c:698-755 */
-                    u32 cid;
-                    if (cur_mode == 0)
-                        cid = c.p1 & 0x3f;
-                    else if (cur_mode == 1)
-                        cid = c.p1 >> 2;
-                    else if (cur_mode == 2)
-                        cid = lutb(K.l0, c.p1) | lutb(K.l1, c.p2);
-                    else
-                        cid = (lutb(K.l2, c.p1) << 3) | lutb(K.l2, c.p2);
-                    desc = rdlane(ltv, cid & 63);
-                }
+                if (ctx) /* context_id(): yeast.c:698-755 */
+                    desc = rdlane(ltv, (lutb(cxa, c.p1) | lutb(cxb, c.p2)) & 63);
                 u32 s = wdec(desc);
                 if (r.rc)
                     break;
