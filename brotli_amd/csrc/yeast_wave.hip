@@ -46,6 +46,7 @@ struct ysw_cfg {
 };
 
 #define RFL(x) uni(x)
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)
 DEV u32 rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 DEV u64 rfl64(u64 x) { return uni64(x); }
 
@@ -232,7 +233,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
     auto refill = [&]() {
         if (r.have <= 32) {
             u32 k = ipos - cbase;
-            if (k >= 64) {
+            if (UNLIKELY(k >= 64)) {
                 cur = nxt;
                 cbase += 64;
                 nxt = load_chunk(cbase + 64);
@@ -247,7 +248,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
     };
     auto wtake = [&](u32 n) -> u32 { /* bits(): yeast.c:163-179 */
         refill();
-        if (n > r.have) {
+        if (UNLIKELY(n > r.have)) {
             rd_eof(r);
             n = 0;
         }
@@ -267,7 +268,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
             e = RFL(t[(e >> 4) + ((peek >> root) & ((1u << (l - root)) - 1))]);
             l = e & 15;
         }
-        if (l > r.have) {
+        if (UNLIKELY(l > r.have)) {
             rd_eof(r);
             l = 0;
         }
@@ -360,6 +361,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
     set_mode();
     u32 descI = c.I.num > 1 ? RFL(itab[c.I.type]) : RFL(itab[0]);
     u32 ltv = ctx ? ltab[(c.L.type << 6) + lane] : 0; /* literal table of each context of this block type */
+    u32 dtv = c.dist_codes > 1 ? dtab[(c.D.type << 2) + (lane & 3)] : 0; /* distance table of each distance context */
     u32 litv = 0;
     u64 got0 = w_got(c);
     u32 maxd = got0 > c.wsize ? c.wsize : (u32)got0;
@@ -371,7 +373,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
     WMARK(7);
     do {
         if (c.I.num > 1) {
-            if (c.I.left == 0) {
+            if (UNLIKELY(c.I.left == 0)) {
                 wswitch(c.I);
                 descI = RFL(itab[c.I.type]);
             }
@@ -386,9 +388,9 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
         u32 ie = rdlane(K.cmd, icode), ce = rdlane(K.cmd, 32 + ccode);
         u32 insert = uni((ie & 0xffff) + wtake(ie >> 16));
         u32 copy = uni((ce & 0xffff) + wtake(ce >> 16));
-        if (r.rc)
+        if (UNLIKELY(r.rc != 0))
             break;
-        if (insert > mlen) {
+        if (UNLIKELY(insert > mlen)) {
             rd_fail(r, YS_INVALID); /* :1189 */
             break;
         }
@@ -402,7 +404,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
             u8 *lbase = c.outp;
             do {
                 if (c.L.num > 1) {
-                    if (c.L.left == 0) {
+                    if (UNLIKELY(c.L.left == 0)) {
                         wswitch(c.L);
                         set_mode();
                         if (ctx)
@@ -414,12 +416,12 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
                 if (ctx) /* context_id(): yeast.c:698-755 */
                     desc = rdlane(ltv, (lutb(cxa, c.p1) | lutb(cxb, c.p2)) & 63);
                 u32 s = wdec(desc);
-                if (r.rc)
+                if (UNLIKELY(r.rc != 0))
                     break;
                 WCOUNT(1);
                 litv = lane == (nl & 63) ? s : litv;
                 nl++;
-                if ((nl & 63) == 0) {
+                if (UNLIKELY((nl & 63) == 0)) {
                     gst8(lbase + lane, litv);
                     lbase += 64;
                 }
@@ -432,7 +434,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
             u32 room = c.wsize - maxd;
             maxd += nl < room ? nl : room;
             WMARK(2);
-            if (r.rc)
+            if (UNLIKELY(r.rc != 0))
                 break;
         }
         if (mlen == 0)
@@ -441,13 +443,16 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
         i64 dist = c.r0;
         if (cmd >= 128) {
             if (c.D.num > 1) {
-                if (c.D.left == 0)
+                if (UNLIKELY(c.D.left == 0)) {
                     wswitch(c.D);
+                    if (c.dist_codes > 1)
+                        dtv = dtab[(c.D.type << 2) + (lane & 3)];
+                }
                 c.D.left--;
             }
             u32 descD = env.descD0;
             if (c.dist_codes > 1)
-                descD = RFL(dtab[(c.D.type << 2) + (copy > 4 ? 3 : copy - 2)]);
+                descD = rdlane(dtv, copy > 4 ? 3 : copy - 2);
             u32 ds = wdec(descD);
             /* distance(): yeast.c:761-789 */
             if (ds < 16) {
@@ -471,13 +476,13 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
                 u64 off = ((u64)(2 + ((nn >> c.postfix) & 1)) << x) - 4;
                 dist = (i64)(((off + wtake(x)) << c.postfix) + (nn & ((1u << c.postfix) - 1)) + c.direct + 1);
             }
-            if (r.rc)
+            if (UNLIKELY(r.rc != 0))
                 break;
             if (ds && dist > 0 && dist <= (i64)maxd) {
                 c.r3 = c.r2; c.r2 = c.r1; c.r1 = c.r0; c.r0 = (u32)dist;
             }
         }
-        if (dist <= 0) {
+        if (UNLIKELY(dist <= 0)) {
             rd_fail(r, YS_INVALID); /* zero: see DESIGN.md; negative: the reference's code 3 */
             break;
         }
@@ -527,7 +532,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
             u32 room = c.wsize - maxd;
             maxd += total < room ? total : room;
         } else {
-            if (copy > mlen) {
+            if (UNLIKELY(copy > mlen)) {
                 rd_fail(r, YS_INVALID); /* :1283 */
                 break;
             }
