@@ -223,6 +223,7 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
         u32 sh = bp & 31;
         cur = load_chunk(cbase);
         nxt = load_chunk(cbase + 64);
+        asm volatile("" : "+v"(cur), "+v"(nxt)); /* landed: see refill */
         u64 lo = rdlane(cur, 0), hi = rdlane(cur, 1);
         r.w = (lo | (hi << 32)) >> sh;
         u32 left = r.total - bitpos;
@@ -237,6 +238,10 @@ DEV void w_commands(WCtx &c, u32 &mlen, const WEnv &env_in, const WConst &K)
                 cur = nxt;
                 cbase += 64;
                 nxt = load_chunk(cbase + 64);
+                /* waited for here, once per 256 bytes of input: a register with a load on its way makes the
+                   compiler wait for ALL loads wherever the loop copies it, and the copy whose bytes are meant to
+                   travel while the next command is decoded would be waited for at the head of every command */
+                asm volatile("" : "+v"(nxt));
                 k -= 64;
             }
             r.w |= (u64)rdlane(cur, k) << r.have;
