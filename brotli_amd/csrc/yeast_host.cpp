@@ -387,7 +387,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         }
     } mark{d, st};
     if (lanes == 0) /* large batches: one stream per lane; small ones: one stream per wavefront, tables in LDS */
-        lanes = env_int("YEAST_LANES", n >= 6144 ? 1 : YS_LANES_WAVE); /* crossover: 44 ms either way at 6,144 streams of 64 KiB (tools/series.sh) */
+        lanes = env_int("YEAST_LANES", n >= 6656 ? 1 : YS_LANES_WAVE); /* crossover: 37 against 41 ms at 6,144 streams of 64 KiB, 43 against 41.5 at 7,168 (tools/series.sh) */
     if (cmp)
         lanes = 64;
     if (lanes != 1 && lanes != 8 && lanes != 16 && lanes != 64 && lanes != YS_LANES_WAVE) {

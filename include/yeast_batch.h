@@ -64,7 +64,7 @@ int yeast_batch(size_t n, void const *const *src, size_t *len, void **dest, size
  *   lanes_per_stream  0 = library default (by batch size), else 1 (batch kernel: one stream per lane) or 8, 16, 64
  *              (cooperative kernel: that many lanes of a wavefront cooperate on one stream); 65 = one wavefront
  *              per stream with the stream's prefix-code tables in LDS (lowest latency; the default below
- *              6,144 streams, 1 from there on)
+ *              6,656 streams, 1 from there on)
  * Calls on one device share the library's per-device counters and table workspaces: a call on another stream
  * than the last one first waits (on the device, through an event) for the last call's kernels, so batches never
  * overlap on one device whatever streams they are given to; calls from several host threads are serialised.
