@@ -30,9 +30,10 @@ DEV u64 rol64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
 #define GAS __attribute__((address_space(1)))
 typedef u32 __attribute__((aligned(1))) u32u;
 typedef u64 __attribute__((aligned(1))) u64u;
-DEV u32 ld32(const u8 *p) { return *(const GAS u32u *)p; }
-DEV u64 ld64(const u8 *p) { return *(const GAS u64u *)p; }
-DEV u32 ld8(const u8 *p) { return *(const GAS u8 *)p; }
+#include "yeast_bounds.h"
+DEV u32 ld32(const u8 *p) { return YSB(p, 4) ? *(const GAS u32u *)p : 0; }
+DEV u64 ld64(const u8 *p) { return YSB(p, 8) ? *(const GAS u64u *)p : 0; }
+DEV u32 ld8(const u8 *p) { return YSB(p, 1) ? *(const GAS u8 *)p : 0; }
 DEV u64 xxh64_round(u64 acc, u64 in) { return rol64(acc + in * P64_2, 31) * P64_1; }
 DEV u64 xxh64_merge(u64 h, u64 v) { return (h ^ xxh64_round(0, v)) * P64_1 + P64_4; }
 
@@ -166,7 +167,7 @@ DEV u32 slice_crc32c(const u32 *tab /*LDS, 4 x 256*/, const u8 *p, u64 len, u32 
     u32 crc = slice == 0 ? ~init : 0xffffffffu;
     u64 i = a;
     for (; i + 32 <= e; i += 32) {
-        u32x4 x = *(const GAS u32x4u *)(p + i), y = *(const GAS u32x4u *)(p + i + 16);
+        u32x4 x = YSB(p + i, 32) ? *(const GAS u32x4u *)(p + i) : (u32x4)0, y = YSB(p + i, 32) ? *(const GAS u32x4u *)(p + i + 16) : (u32x4)0;
         crc = crc_word(tab, crc, x.x);
         crc = crc_word(tab, crc, x.y);
         crc = crc_word(tab, crc, x.z);
@@ -481,3 +482,5 @@ extern "C" int ys_launch_xxh_digest(unsigned is64, const u64 *v, u64 total, u64 
     hipLaunchKernelGGL(k_xxh_digest, dim3(1), dim3(64), 0, (hipStream_t)stream, is64, v, total, seed, mem, memsize, out);
     return (int)hipGetLastError();
 }
+
+YSB_HOST(check) /* bounds-checked debug build only: yeast_bounds.h */

@@ -107,6 +107,7 @@ extern "C" int ys_static_init(int device)
 }
 extern "C" unsigned ys_static_max_streams(void) { return YS_STATIC_MAX_STREAMS; }
 extern "C" size_t ys_static_bytes(void) { return sizeof(scratch); }
+extern "C" const void *ys_static_ptr(int device) { return device >= 0 && device < 64 ? g_scratch_ptr[device] : nullptr; }
 
 __global__ void k_static_reset(u32 *counters) { counters[threadIdx.x] = 0; } /* the 256 bytes of counters */
 
@@ -136,3 +137,5 @@ extern "C" int ys_launch_decode_static(const ys_params *p_in, int device, void *
     p.ws_stride = YS_STATIC_SLOT;
     return launch_decode_t<64, false>(p, YS_STATIC_GROUPS, st);
 }
+
+YSB_HOST(decode) /* bounds-checked debug build only: yeast_bounds.h */

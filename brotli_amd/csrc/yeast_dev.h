@@ -14,49 +14,64 @@
 /* every access below is to global memory: say so, or pointers that travelled through an
    out-of-line call are treated as generic and cost flat_* instructions */
 #define GAS __attribute__((address_space(1)))
-DEV u32 gld8(const void *p) { return *(const GAS u8 *)p; }
-DEV u32 gld16(const void *p) { return *(const GAS u16 *)p; }
-DEV u32 gld32(const void *p) { return *(const GAS u32 *)p; }
+#include "yeast_bounds.h" /* YSB(p, n): true, unless this is the bounds-checked debug build and the access is out of range */
+DEV u32 gld8(const void *p) { return YSB(p, 1) ? *(const GAS u8 *)p : 0; }
+DEV u32 gld16(const void *p) { return YSB(p, 2) ? *(const GAS u16 *)p : 0; }
+DEV u32 gld32(const void *p) { return YSB(p, 4) ? *(const GAS u32 *)p : 0; }
 DEV u64 gld64u(const void *p) /* unaligned */
 {
     typedef u64 __attribute__((aligned(1))) u64u;
-    return *(const GAS u64u *)p;
+    return YSB(p, 8) ? *(const GAS u64u *)p : 0;
 }
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 DEV u32x4 gld128u(const void *p) /* unaligned */
 {
     typedef u32x4 __attribute__((aligned(1))) u32x4u;
-    return *(const GAS u32x4u *)p;
+    return YSB(p, 16) ? *(const GAS u32x4u *)p : (u32x4)0;
 }
 /* the same with the streaming hint: the line is not kept in L2 for this access */
 DEV u32x4 gld128u_nt(const void *p)
 {
     typedef u32x4 __attribute__((aligned(1))) u32x4u;
-    return __builtin_nontemporal_load((const GAS u32x4u *)p);
+    return YSB(p, 16) ? __builtin_nontemporal_load((const GAS u32x4u *)p) : (u32x4)0;
 }
 DEV void gst128u(void *p, u32x4 v)
 {
     typedef u32x4 __attribute__((aligned(1))) u32x4u;
-    *(GAS u32x4u *)p = v;
+    if (YSB(p, 16))
+        *(GAS u32x4u *)p = v;
 }
 DEV u32 gld16u(const void *p) /* unaligned */
 {
     typedef u16 __attribute__((aligned(1))) u16u;
-    return *(const GAS u16u *)p;
+    return YSB(p, 2) ? *(const GAS u16u *)p : 0;
 }
-DEV void gst8(void *p, u32 v) { *(GAS u8 *)p = (u8)v; }
-DEV void gst16(void *p, u32 v) { *(GAS u16 *)p = (u16)v; }
-DEV void gst32(void *p, u32 v) { *(GAS u32 *)p = v; }
-DEV void gst64(void *p, u64 v) { *(GAS u64 *)p = v; }
+DEV void gst8(void *p, u32 v) { if (YSB(p, 1)) *(GAS u8 *)p = (u8)v; }
+DEV void gst16(void *p, u32 v) { if (YSB(p, 2)) *(GAS u16 *)p = (u16)v; }
+DEV void gst32(void *p, u32 v) { if (YSB(p, 4)) *(GAS u32 *)p = v; }
+DEV void gst64(void *p, u64 v) { if (YSB(p, 8)) *(GAS u64 *)p = v; }
 DEV void gst32u(void *p, u32 v) /* unaligned */
 {
     typedef u32 __attribute__((aligned(1))) u32u;
-    *(GAS u32u *)p = v;
+    if (YSB(p, 4))
+        *(GAS u32u *)p = v;
 }
 DEV void gst64u(void *p, u64 v)
 {
     typedef u64 __attribute__((aligned(1))) u64u;
-    *(GAS u64u *)p = v;
+    if (YSB(p, 8))
+        *(GAS u64u *)p = v;
+}
+DEV void gst16u(void *p, u32 v) /* unaligned */
+{
+    typedef u16 __attribute__((aligned(1))) u16u;
+    if (YSB(p, 2))
+        *(GAS u16u *)p = (u16)v;
+}
+DEV u32 gld32u(const void *p) /* unaligned */
+{
+    typedef u32 __attribute__((aligned(1))) u32u;
+    return YSB(p, 4) ? *(const GAS u32u *)p : 0;
 }
 
 /* A long copy by a whole wavefront (64 lanes): n bytes from d bytes back, d >= n or d >= 1024.  Byte-serial semantics

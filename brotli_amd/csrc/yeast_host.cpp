@@ -145,6 +145,7 @@ struct Device {
     u8 *d_dict = nullptr, *d_xf = nullptr;
     u8 *d_xdict = nullptr;   /* every transform of every dictionary word, ~19 MB (yeast_lane.hip k_expand_dict) */
     u32 *d_xbase = nullptr;  /* [121][21] offsets into it */
+    size_t xdict_bytes = 0;
     int cus = 256;
     Buf src, dst, soff, doff, rec, ws, ws_big, ctr, scratch;
     Buf pin;    /* pinned host staging for the outputs of a large host-pointer batch */
@@ -235,6 +236,7 @@ static int device_get(Device **out)
                 }
             }
             HIPCK(hipMalloc((void **)&d.d_xdict, total + 64));
+            d.xdict_bytes = total + 64;
             HIPCK(hipMemset(d.d_xdict, 0, total + 64));
             HIPCK(hipMalloc((void **)&d.d_xbase, base.size() * 4));
             HIPCK(hipMemcpy(d.d_xbase, base.data(), base.size() * 4, hipMemcpyHostToDevice));
@@ -330,7 +332,7 @@ static const char *const KNOB_NAMES[] = {"YEAST_LANES", "YEAST_WAVES_PER_CU", "Y
                                          "YEAST_WS_KB", "YEAST_LEAN_ROOT_LIT", "YEAST_LEAN_ROOT_IAC",
                                          "YEAST_LEAN_ROOT_DIST", "YEAST_SORT", "YEAST_DEBUG", "YEAST_HOST_THREADS",
                                          "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB", "YEAST_MERGE", "YEAST_PAIR",
-                                         "YEAST_HOST_FLOOR", "YEAST_D2H_PIN_KB"};
+                                         "YEAST_HOST_FLOOR", "YEAST_D2H_PIN_KB", "YEAST_BOUNDS_SHRINK"};
 enum { KNOBS = sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]) };
 static int g_knob_val[KNOBS];
 static bool g_knob_set[KNOBS];
@@ -359,10 +361,141 @@ extern "C" void yeast_reload_knobs(void)
     load_knobs();
 }
 
+#ifdef YS_BOUNDS
+/* ---- the bounds-checked debug build (yeast_bounds.h): the ranges the kernels of one call may touch, written into
+   every code object before its launches; the count of accesses outside them read back after the call ---- */
+#include "yeast_bounds.h"
+extern "C" {
+int ysb_set_check(const ys_bounds_t *), ysb_get_check(ys_bounds_t *), ysb_set_decode(const ys_bounds_t *),
+    ysb_get_decode(ys_bounds_t *), ysb_set_wave(const ys_bounds_t *), ysb_get_wave(ys_bounds_t *),
+    ysb_set_lane(const ys_bounds_t *), ysb_get_lane(ys_bounds_t *);
+const void *ys_static_ptr(int device);
+}
+static const char *g_ysb_name[YSB_MAX];
+static void ysb_add(ys_bounds_t &b, const char *name, const void *p, size_t n)
+{
+    if (b.n >= YSB_MAX)
+        return;
+    g_ysb_name[b.n] = name; /* a buffer that does not exist yet keeps its place in the list (an empty range) */
+    b.lo[b.n] = p && n ? (unsigned long long)(size_t)p : 0;
+    b.hi[b.n] = p && n ? b.lo[b.n] + n : 0;
+    b.n++;
+}
+static int ysb_set_all(const ys_bounds_t &b)
+{
+    int e = ysb_set_check(&b);
+    e = e ? e : ysb_set_decode(&b);
+    e = e ? e : ysb_set_wave(&b);
+    e = e ? e : ysb_set_lane(&b);
+    return e;
+}
+/* what the launches of the call so far have counted, by code object (writing a new list clears the device's counts) */
+static ys_bounds_t g_ysb_got[4];
+static int ysb_collect(void)
+{
+    ys_bounds_t now[4];
+    memset(now, 0, sizeof(now));
+    int e = ysb_get_check(&now[0]);
+    e = e ? e : ysb_get_decode(&now[1]);
+    e = e ? e : ysb_get_wave(&now[2]);
+    e = e ? e : ysb_get_lane(&now[3]);
+    for (int k = 0; k < 4 && !e; k++) {
+        if (!now[k].hits)
+            continue;
+        unsigned before = g_ysb_got[k].hits;
+        if (!before)
+            g_ysb_got[k] = now[k];
+        g_ysb_got[k].hits = before + now[k].hits;
+    }
+    return e;
+}
+/* called before each launch of a checked call (the library's buffers may have grown since the last one) */
+static int ysb_arm(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64 *doff, ys_record *rec, size_t n)
+{
+    u64 send = 0, dend = 0;
+    HIPCK(hipMemcpy(&send, soff + n, 8, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(&dend, doff + n, 8, hipMemcpyDeviceToHost));
+    /* self-test of the checker: declare the output arena this many bytes shorter than it is */
+    u64 shrink = (u64)env_int("YEAST_BOUNDS_SHRINK", 0);
+    dend -= shrink < dend ? shrink : dend;
+    int id = 0;
+    HIPCK(hipGetDevice(&id));
+    ys_bounds_t b;
+    memset(&b, 0, sizeof(b));
+    ysb_add(b, "dictionary", d.d_dict, sizeof(ys_dictionary) + 64); /* range 0: what a refused LDS-landing load reads instead */
+    ysb_add(b, "transforms", d.d_xf, 4096);
+    ysb_add(b, "expanded dictionary", d.d_xdict, d.xdict_bytes);
+    ysb_add(b, "expanded dictionary index", d.d_xbase, 121 * 21 * 4);
+    ysb_add(b, "table workspace", d.ws.p, d.ws.cap);
+    ysb_add(b, "retry workspace", d.ws_big.p, d.ws_big.cap);
+    ysb_add(b, "counters and lists", d.ctr.p, d.ctr.cap);
+    ysb_add(b, "static workspace", ys_static_ptr(id), ys_static_bytes());
+    ysb_add(b, "d_src (+ YEAST_SRC_PAD)", src, send + YS_SRC_PAD);
+    ysb_add(b, "d_src_off", soff, (n + 1) * 8);
+    ysb_add(b, "d_dst", dst, dend);
+    ysb_add(b, "d_dst_off", doff, (n + 1) * 8);
+    ysb_add(b, "d_rec", rec, n * sizeof(ys_record));
+    int e = ysb_collect(); /* waits for the launches so far */
+    e = e ? e : ysb_set_all(b);
+    if (e)
+        return fail("bounds list upload", (hipError_t)e);
+    return 0;
+}
+/* after the call: waits for the device, reads the counts, switches checking off again; -1 if anything was refused */
+static int ysb_verdict(void)
+{
+    HIPCK(hipDeviceSynchronize());
+    int e = ysb_collect();
+    ys_bounds_t got[4];
+    memcpy(got, g_ysb_got, sizeof(got));
+    memset(g_ysb_got, 0, sizeof(g_ysb_got));
+    ys_bounds_t off;
+    memset(&off, 0, sizeof(off));
+    e = e ? e : ysb_set_all(off);
+    if (e)
+        return fail("bounds list read-back", (hipError_t)e);
+    static const char *const tu[4] = {"check", "cooperative/retry", "wavefront-per-stream", "batch"};
+    for (int k = 0; k < 4; k++) {
+        if (!got[k].hits)
+            continue;
+        /* the nearest range, for the message */
+        unsigned best = 0;
+        unsigned long long bd = ~0ull;
+        for (unsigned i = 0; i < got[k].n; i++) {
+            if (!got[k].hi[i])
+                continue;
+            unsigned long long a = got[k].addr, dd = a < got[k].lo[i] ? got[k].lo[i] - a : a >= got[k].hi[i] ? a - got[k].hi[i] + 1 : 0;
+            if (dd < bd) {
+                bd = dd;
+                best = i;
+            }
+        }
+        snprintf(t_err, sizeof(t_err),
+                 "libyeast (bounds build): %u access%s of the %s kernels outside every buffer; the first: %u bytes at %#llx, "
+                 "%lld bytes %s %s [%#llx, %#llx)",
+                 got[k].hits, got[k].hits == 1 ? "" : "es", tu[k], got[k].size, got[k].addr,
+                 (long long)(got[k].addr < got[k].lo[best] ? got[k].lo[best] - got[k].addr : got[k].addr + got[k].size - got[k].hi[best]),
+                 got[k].addr < got[k].lo[best] ? "before" : "past the end of", g_ysb_name[best], got[k].lo[best], got[k].hi[best]);
+        fprintf(stderr, "%s\n", t_err);
+        for (int j = 0; j < 6 && (unsigned)j + 1 < got[k].hits; j++)
+            fprintf(stderr, "  then %u bytes at %#llx\n", (unsigned)(got[k].more[j] >> 56), got[k].more[j] & 0xffffffffffffffull);
+        return -1;
+    }
+    return 0;
+}
+#define YSB_ARM()                                                                                                      \
+    do {                                                                                                               \
+        if (ysb_arm(d, src, soff, dst, doff, rec, n))                                                                  \
+            return -1;                                                                                                 \
+    } while (0)
+#else
+#define YSB_ARM() do { } while (0)
+#endif
+
 /* Enqueue decode (+ retry pass for streams whose tables did not fit the
    default arena, + check values) for n streams.  Everything is device
-   resident; nothing here synchronises. */
-static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64 *doff, ys_record *rec, size_t n,
+   resident; nothing here synchronises (the bounds-checked debug build does). */
+static int enqueue_impl(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64 *doff, ys_record *rec, size_t n,
                    unsigned check_kind, int lanes, int cmp, hipStream_t st)
 {
     if (n == 0)
@@ -443,6 +576,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
         p.ws = (u8 *)d.ws.p;
         p.ws_stride = stride;
         snprintf(t_kernel, sizeof(t_kernel), "k_decode_wave");
+        YSB_ARM();
         e = ysw_launch(&p, slot_entries, rootcaps, blocks, st);
         if (e)
             return fail("decode launch", (hipError_t)e);
@@ -484,6 +618,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
                  rd = (unsigned)env_int("YEAST_LEAN_ROOT_DIST", 7);
         auto clamp = [](unsigned v) { return v < 4 ? 4u : v > 8 ? 8u : v; };
         p.rootcaps = 8u | (clamp(rl) << 8) | (clamp(ri) << 16) | (clamp(rd) << 24);
+        YSB_ARM();
         if (env_int("YEAST_SORT", 1)) { /* hand the streams out by size class, longest first (yeast_lane.hip) */
             u32 *order = p.retry_list + n;
             e = ysl_order(soff, (unsigned)n, (u32 *)d.ctr.p + 4, order, st);
@@ -512,6 +647,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     }
     else {
         snprintf(t_kernel, sizeof(t_kernel), "k_decode<%d, %s>", lanes, cmp ? "true" : "false");
+        YSB_ARM();
         e = ys_launch_decode(&p, lanes, cmp, groups, st);
     }
     if (e)
@@ -527,6 +663,7 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
     p.counter = (u32 *)d.ctr.p + 1;
     p.retry = 1;
     p.rootcaps = 0;
+    YSB_ARM();
     e = ys_launch_decode(&p, 64, cmp, big_groups, st);
     if (e)
         return fail("retry launch", (hipError_t)e);
@@ -537,6 +674,19 @@ static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64
             return fail("check launch", (hipError_t)e);
     }
     return 0;
+}
+
+static int enqueue(Device &d, const u8 *src, const u64 *soff, u8 *dst, const u64 *doff, ys_record *rec, size_t n,
+                   unsigned check_kind, int lanes, int cmp, hipStream_t st)
+{
+    int e = enqueue_impl(d, src, soff, dst, doff, rec, n, check_kind, lanes, cmp, st);
+#ifdef YS_BOUNDS
+    if (n) {
+        int v = ysb_verdict();
+        e = e ? e : v;
+    }
+#endif
+    return e;
 }
 
 extern "C" int yeast_batch_device(const void *d_src, const uint64_t *d_src_off, void *d_dst,

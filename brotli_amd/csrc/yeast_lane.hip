@@ -203,3 +203,5 @@ extern "C" int ysl_launch(const ys_params *p, int half, int merge, unsigned stre
         return launch_lean_t<16>(*p, streams, (hipStream_t)stream);
     return half ? launch_lean_t<32>(*p, streams, (hipStream_t)stream) : launch_lean_t<64>(*p, streams, (hipStream_t)stream);
 }
+
+YSB_HOST(lane) /* bounds-checked debug build only: yeast_bounds.h */

@@ -296,13 +296,11 @@ DEV void put_le(u8 *p, u64 v, u32 n)
     }
     u32 o = 0;
     if (n & 4) {
-        typedef u32 __attribute__((aligned(1))) u32u;
-        *(GAS u32u *)p = (u32)v;
+        gst32u(p, (u32)v);
         o = 4;
     }
     if (n & 2) {
-        typedef u16 __attribute__((aligned(1))) u16u;
-        *(GAS u16u *)(p + o) = (u16)(v >> (8 * o));
+        gst16u(p + o, (u32)(v >> (8 * o)));
         o += 2;
     }
     if (n & 1)
@@ -356,13 +354,11 @@ DEV void copy_exact(u8 *dst, u32 n, u32 d, u32 sub)
         } else if (G == 1 || sub == 0) {
             u32 o = 0;
             if (n & 4) {
-                typedef u32 __attribute__((aligned(1))) u32u;
-                *(GAS u32u *)dst = *(const GAS u32u *)from;
+                gst32u(dst, gld32u(from));
                 o = 4;
             }
             if (n & 2) {
-                typedef u16 __attribute__((aligned(1))) u16u;
-                *(GAS u16u *)(dst + o) = *(const GAS u16u *)(from + o);
+                gst16u(dst + o, gld16u(from + o));
                 o += 2;
             }
             if (n & 1)

@@ -88,13 +88,13 @@ DEV void trip_shared_fill(TripShared &ts, const u8 *xforms, const u32 *xbase)
 }
 
 /* global memory through a wavefront-uniform base and a 32-bit lane offset */
-DEV u32 sld16(const u8 *base, u32 off) { return *(const GAS u16 *)(base + (u64)off); }
-DEV u32 sld32(const u8 *base, u32 off) { return *(const GAS u32 *)(base + (u64)off); }
-DEV u32 sld8(const u8 *base, u32 off) { return *(const GAS u8 *)(base + (u64)off); }
+DEV u32 sld16(const u8 *base, u32 off) { return YSB(base + (u64)off, 2) ? *(const GAS u16 *)(base + (u64)off) : 0; }
+DEV u32 sld32(const u8 *base, u32 off) { return YSB(base + (u64)off, 4) ? *(const GAS u32 *)(base + (u64)off) : 0; }
+DEV u32 sld8(const u8 *base, u32 off) { return YSB(base + (u64)off, 1) ? *(const GAS u8 *)(base + (u64)off) : 0; }
 DEV u32x4 sld128(const u8 *base, u32 off) /* 4-byte aligned */
 {
     typedef u32x4 __attribute__((aligned(4))) u32x4a;
-    return *(const GAS u32x4a *)(base + (u64)off);
+    return YSB(base + (u64)off, 16) ? *(const GAS u32x4a *)(base + (u64)off) : (u32x4)0;
 }
 
 #define YT_CMD 0u
@@ -135,14 +135,21 @@ struct TripOut {
    load, tools/ubench/glds_issue.hip.) */
 DEV void lds_load4(const u8 *sbase, u32 voff, u32 lds)
 {
+    voff = YSB(sbase + (u64)voff, 4) ? voff : 0u; /* bounds-checked build: a load out of range reads the base instead */
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 DEV void lds_load16(const u8 *src, u32 lds)
 {
+#ifdef YS_BOUNDS
+    src = YSB(src, 16) ? src : (const u8 *)(size_t)g_ysb.lo[0];
+#endif
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds) : "memory");
 }
 DEV void lds_load16_nt(const u8 *src, u32 lds) /* read once: not worth a place in L2 */
 {
+#ifdef YS_BOUNDS
+    src = YSB(src, 16) ? src : (const u8 *)(size_t)g_ysb.lo[0];
+#endif
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(src), "s"(lds) : "memory");
 }
 

@@ -953,3 +953,5 @@ extern "C" int ysw_launch(const ys_params *p, unsigned slot_entries, unsigned ro
     hipLaunchKernelGGL(k_decode_wave, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *p, cfg);
     return (int)hipGetLastError();
 }
+
+YSB_HOST(wave) /* bounds-checked debug build only: yeast_bounds.h */
