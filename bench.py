@@ -278,6 +278,28 @@ def main():
         except Exception:
             traffic = None
 
+    # the launch against the three ceilings that have been measured for it: HBM bytes, the rate at
+    # which HBM serves unrelated 64-byte lines, the instruction issue rate of one wavefront over the longest stream.
+    # Each: the time the ceiling alone would allow, and that time as a fraction of the kernel time measured just now.
+    ceilings = {"hbm_bytes": {"bound_ms": algo / (HBM_PEAK_GBS * 1e9) * 1e3,
+                              "frac": algo / (HBM_PEAK_GBS * 1e9) * 1e3 / k_ms}}
+    cf = os.path.join(ROOT, "profiles", "r03", "ceilings.json")
+    if os.path.exists(cf):
+        try:
+            c = json.load(open(cf))
+            if c.get("streams") == n and kernel and kernel in str(c.get("kernel", "")):
+                hl, it = c["hbm_lines"], c["issue"]
+                b1 = hl["lines_per_launch"] / hl["ceiling_lines_per_s"] * 1e3
+                b2 = it["longest_stream_trips"] * it["instructions_per_trip"] * it["cycles_per_instruction"] / (it["clock_ghz"] * 1e9) * 1e3
+                ceilings["hbm_lines"] = {"bound_ms": b1, "frac": b1 / k_ms, "lines_per_launch": hl["lines_per_launch"],
+                                         "ceiling_lines_per_s": hl["ceiling_lines_per_s"]}
+                ceilings["wavefront_issue"] = {"bound_ms": b2, "frac": b2 / k_ms,
+                                               **{k: it[k] for k in ("longest_stream_trips", "instructions_per_trip",
+                                                                     "cycles_per_instruction", "clock_ghz")}}
+                ceilings["source"] = "profiles/r03/ceilings.json (counters and listing of %s at %d streams)" % (c["kernel"], n)
+        except Exception:
+            pass
+
     line = {
         "metric": "decompressed GB/s (whole node), batched 64 KiB brotli streams",
         "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -297,7 +319,8 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "algorithmic_bytes_per_launch": algo, "kernel_ms": k_ms, "check_kernel_ms": c_ms,
                      "measured_copy_GBs": copy_gbs,
-                     "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None},
+                     "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
+                     "ceilings": ceilings},
     }
     series = os.path.join(ROOT, "profiles", "r03", "stream_series.json")
     if not os.path.exists(series):
