@@ -57,10 +57,6 @@ typedef struct {
     const u8 *xforms;    /* 121 x 20-byte transform records */
     const u8 *xdict;     /* every transform of every dictionary word (built on the device at start-up) */
     const u32 *xdict_base; /* [121][21]: byte offset in xdict of (transform, word length 4..24), entries back to back */
-    const u32 *maxlen;   /* batch kernel: the longest stream's compressed bytes (written by the hand-out order's kernels) */
-    u32 pace;            /* batch kernel, one round with every block resident: a wavefront whose streams are shorter than the
-                            longest idles between trips, pace / 16 x 128 cycles per trip and unit of (longest / own - 1),
-                            so that the memory system's transaction rate goes to the wavefronts the launch waits for; 0 = off */
     u32 rootcaps;        /* root table widths: other | literal << 8 | insert-and-copy << 16 | distance << 24;
                             0 = 8 bits everywhere (the only setting of the kernels other than the lean one) */
 } ys_params;

@@ -41,7 +41,6 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
        takes it from the end, so the wavefront with the longest streams shares its SIMD with the one that has the shortest
        and has it to itself soonest.  Later rounds, if any, take what is left in order. */
     bool first = (p.debug & 2) != 0 && !p.retry;
-    bool paced = first;
     const u32 nblk = gridDim.x;
     for (;;) {
         u32 base = 0;
@@ -58,35 +57,11 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
         if (base >= limit)
             break;
         u32 job = base + slot;
-        const bool mine = slot < S && job < limit;
-        if (mine) {
+        if (slot < S && job < limit) {
             if (p.retry)
                 job = p.retry_list[job];
             else if (p.order)
                 job = p.order[job];
-        }
-        /* Pacing (one round, every block resident: the launch lasts as long as the wavefronts with the longest streams, and
-           while all 65,536 streams run the memory system is at its transaction rate).  A wavefront whose streams are shorter
-           idles between trips in proportion to what it has to spare, so that it ends about when the longest do and the
-           transactions it does not ask for meanwhile go to them.  It decides when a trip runs, never what it decodes. */
-        u32 pace = 0;
-        if (p.pace && paced) {
-            u64 len = mine ? p.src_off[job + 1] - p.src_off[job] : 0;
-            u32 l32 = len > 0x7fffffffull ? 0x7fffffffu : (u32)len, lw = 0;
-            for (u64 todo = __ballot(1); todo; todo &= todo - 1) {
-                u32 v = (u32)__builtin_amdgcn_readlane((int)l32, (int)__builtin_ctzll(todo));
-                lw = v > lw ? v : lw;
-            }
-            const u32 lmax = __builtin_amdgcn_readfirstlane(*p.maxlen);
-            if (lw && lmax > lw) {
-                u64 units = ((u64)p.pace * (lmax - lw) / lw) >> 4;
-                pace = units > 64 ? 64u : (u32)units;
-            }
-        }
-        paced = false;
-        if (slot == 0)
-            wlds[lane >> 6].pace[0] = pace;
-        if (mine) {
             decode_stream<1, false, S | (UNIT << 8)>(p, job, ws, shp, 0, &wlds[lane >> 6], tsp, wbase);
         }
     }
@@ -134,27 +109,19 @@ DEV u32 order_bin(u64 len)
 }
 /* both counting kernels count inside the block first (LDS atomics) and touch a global counter once
    per block and class: 65,536 streams fall into a few dozen classes */
-__global__ __launch_bounds__(256) void k_order_hist(const u64 *src_off, u32 n, u32 *bins, u32 *maxlen)
+__global__ __launch_bounds__(256) void k_order_hist(const u64 *src_off, u32 n, u32 *bins)
 {
     __shared__ u32 cnt[YS_ORDER_BINS];
-    __shared__ u32 longest;
-    if (threadIdx.x == 0)
-        longest = 0;
     for (u32 k = threadIdx.x; k < YS_ORDER_BINS; k += 256)
         cnt[k] = 0;
     __syncthreads();
     u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        u64 len = src_off[i + 1] - src_off[i];
-        atomicAdd(cnt + order_bin(len), 1u);
-        atomicMax(&longest, len > 0x7fffffffull ? 0x7fffffffu : (u32)len);
-    }
+    if (i < n)
+        atomicAdd(cnt + order_bin(src_off[i + 1] - src_off[i]), 1u);
     __syncthreads();
     for (u32 k = threadIdx.x; k < YS_ORDER_BINS; k += 256)
         if (cnt[k])
             atomicAdd(bins + k, cnt[k]);
-    if (threadIdx.x == 0)
-        atomicMax(maxlen, longest);
 }
 __global__ __launch_bounds__(YS_ORDER_BINS) void k_order_scan(u32 *bins)
 {
@@ -190,12 +157,12 @@ __global__ __launch_bounds__(256) void k_order_scatter(const u64 *src_off, u32 n
         order[cnt[b] + rank] = i;
 }
 
-/* bins: YS_ORDER_BINS zeroed counters; maxlen: a zeroed counter (the longest stream's bytes); order: n entries */
-extern "C" int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *maxlen, u32 *order, void *stream)
+/* bins: YS_ORDER_BINS zeroed counters; order: n entries */
+extern "C" int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *order, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     unsigned blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_order_hist, dim3(blocks), dim3(256), 0, st, src_off, n, bins, maxlen);
+    hipLaunchKernelGGL(k_order_hist, dim3(blocks), dim3(256), 0, st, src_off, n, bins);
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(YS_ORDER_BINS), 0, st, bins);
     hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(256), 0, st, src_off, n, bins, order);
     return (int)hipGetLastError();

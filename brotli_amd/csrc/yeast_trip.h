@@ -51,7 +51,6 @@ struct TripLds {
     u32x4 unit[64]; /* UNIT form of the loop: the output unit being put together (a piece and the literals behind it);
                        RING form: where a piece taken from the ring waits for the next trip */
     u8 ring[S * YT_RING_STRIDE + 16]; /* RING form: the last 64 bytes of each stream's output (see run_trip_fn) */
-    u32 pace[4]; /* [0]: units of 128 cycles this wavefront idles after every trip (yeast_lane.hip; third loop form only) */
 };
 
 /* LDS image shared by the wavefronts of a block */

@@ -48,7 +48,6 @@ NOINL TripOut run_trip3_fn(TripIn a)
     const u32 out_lo = (u32)(uintptr_t)a.out;
     u32 mlen = a.mlen;
     u32 rc = 0, dry = 0;
-    const u32 pace = uni(wl->pace[0]);
     const u32 lds_ent = uni((u32)(uintptr_t)&wl->ent[0]);
     const u32 lds_top = uni((u32)(uintptr_t)&wl->top[0]);
     const u32 lds_piece = uni((u32)(uintptr_t)&wl->piece[0]);
@@ -532,9 +531,6 @@ NOINL TripOut run_trip3_fn(TripIn a)
         }
 #endif
         TMARK(7);
-        if (pace) /* a wavefront with time to spare leaves the memory system to those without (yeast_lane.hip) */
-            for (u32 i = 0; i < pace; i++)
-                __builtin_amdgcn_s_sleep(2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef YS_PROFILE
