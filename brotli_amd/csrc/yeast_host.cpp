@@ -332,7 +332,7 @@ static const char *const KNOB_NAMES[] = {"YEAST_LANES", "YEAST_WAVES_PER_CU", "Y
                                          "YEAST_WS_KB", "YEAST_LEAN_ROOT_LIT", "YEAST_LEAN_ROOT_IAC",
                                          "YEAST_LEAN_ROOT_DIST", "YEAST_SORT", "YEAST_DEBUG", "YEAST_HOST_THREADS",
                                          "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB", "YEAST_MERGE", "YEAST_PAIR",
-                                         "YEAST_HOST_FLOOR", "YEAST_D2H_PIN_KB", "YEAST_BOUNDS_SHRINK"};
+                                         "YEAST_HOST_FLOOR", "YEAST_D2H_PIN_KB", "YEAST_BOUNDS_SHRINK", "YEAST_CHUNK64_FROM"};
 enum { KNOBS = sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]) };
 static int g_knob_val[KNOBS];
 static bool g_knob_set[KNOBS];
@@ -594,7 +594,11 @@ static int enqueue_impl(Device &d, const u8 *src, const u64 *soff, u8 *dst, cons
        trip done per symbol kind (yeast_trip3.h): 41.3 ms at 8,192 streams, 43.0 at 32,768, 46.5 at 65,536 -- as fast as the
        plain loop (0: 41.1 at 8,192) where a wavefront has its SIMD to itself and faster than the earlier write-behind
        loop (2: 45.2 / 46.0 / 47.8) everywhere, so one form serves all batch sizes.  0, 1, 2 stay selectable (tests, A/B) */
-    const int merge = flat ? env_int("YEAST_MERGE", 3) : 0;
+    /* 3 and 4 are the same loop with 64-byte and with 16-byte output chunks: whole lines for batches that keep every SIMD
+       busy with two wavefronts (a chunk is evicted from L2 before its line is complete: 45.6 -> 44.0 ms at 65,536 streams,
+       160.5 -> 151.3 at 262,144), the shorter trip below that (40.1 against 41.2 ms at 8,192; the two meet between 16,384
+       and 24,576 streams) */
+    const int merge = flat ? env_int("YEAST_MERGE", n > (size_t)d.cus * (size_t)env_int("YEAST_CHUNK64_FROM", 80) ? 3 : 4) : 0;
     const int half = flat ? env_int("YEAST_HALF", merge >= 2 && n > (size_t)d.cus * 256 ? 0 : 1) : 0;
     unsigned per_block = 256u / (unsigned)lanes / (half == 2 ? 4u : half ? 2u : 1u);
     /* full wavefronts with the ring: 110 KB of LDS per block, one block per CU */

@@ -192,6 +192,10 @@ extern "C" int ysl_launch(const ys_params *p, int half, int merge, unsigned stre
         return launch_lean_t<32, 3>(*p, streams, (hipStream_t)stream);
     if (half == 0 && merge == 3)
         return launch_lean_t<64, 3>(*p, streams, (hipStream_t)stream);
+    if (half == 1 && merge == 4)
+        return launch_lean_t<32, 4>(*p, streams, (hipStream_t)stream);
+    if (half == 0 && merge == 4)
+        return launch_lean_t<64, 4>(*p, streams, (hipStream_t)stream);
     if (half == 1 && merge == 2)
         return launch_lean_t<32, 2>(*p, streams, (hipStream_t)stream);
     if (half == 0 && merge == 2)

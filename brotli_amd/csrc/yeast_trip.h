@@ -36,6 +36,7 @@
    [0, 16) is written at [64, 80) too and the other way round, so sixteen bytes can be read or written at any offset
    below 64 in one piece; 37 words: the streams' rings start in different banks) */
 #define YT_RING_STRIDE 148
+#define YT_RING_ALLOC 180 /* bytes per stream the ring array is sized for: the third loop form's layout (yeast_trip3.h) */
 typedef u32x4 __attribute__((aligned(1))) u32x4u;
 
 /* per-wavefront LDS: [index][stream], so the streams of a wavefront use different banks */
@@ -50,7 +51,8 @@ struct TripLds {
     u32x4 piece[64];
     u32x4 unit[64]; /* UNIT form of the loop: the output unit being put together (a piece and the literals behind it);
                        RING form: where a piece taken from the ring waits for the next trip */
-    u8 ring[S * YT_RING_STRIDE + 16]; /* RING form: the last 64 bytes of each stream's output (see run_trip_fn) */
+    u8 ring[S * YT_RING_ALLOC + 16]; /* RING form: the last 64 bytes of each stream's output (see run_trip_fn); third form: the
+                                        last 128 (yeast_trip3.h) */
 };
 
 /* LDS image shared by the wavefronts of a block */
@@ -829,7 +831,9 @@ DEV void run_trip(Ctx &c, u32 &mlen, const FlatEnv &fe)
 #endif
     TripOut o;
     if constexpr ((SF >> 8) == 3)
-        o = run_trip3_fn<(SF & 0xff)>(a);
+        o = run_trip3_fn<(SF & 0xff), 128u, 64u>(a);
+    else if constexpr ((SF >> 8) == 4)
+        o = run_trip3_fn<(SF & 0xff), 64u, 16u>(a);
     else
         o = run_trip_fn<SF>(a);
     c.outp = o.outp;

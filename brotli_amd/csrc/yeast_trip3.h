@@ -30,9 +30,30 @@
 
 typedef u16 __attribute__((aligned(1))) u16u;
 
-template <int S>
+/* The stream's ring in LDS: the last RING bytes of its output at offset (position & (RING - 1)), 16 bytes of slack in front,
+   and behind it a copy of its first 16 bytes (so that 16 bytes can be read at any offset) and 16 bytes that take the second
+   write of an access that needs none.  Output leaves it in complete chunks of CHUNK bytes.  Two settings:
+     RING 128, CHUNK 64 (loop form 3): for batches that keep every SIMD busy.  With every stream resident a chunk is evicted
+       from L2 before the next one of its line arrives, so a 16-byte chunk costs a 32-byte write of its own (WRITE_SIZE 174 KB
+       per stream against 87 KB at 8,192 streams, profiles/r03/write_traffic.txt); a 64-byte chunk is a whole line, written
+       once: 45.6 -> 44.0 ms at 65,536 streams, 160.5 -> 151.3 at 262,144;
+     RING 64, CHUNK 16 (loop form 4): for smaller batches, where the chunks merge in L2 anyway and the shorter trip counts
+       (40.1 against 40.9 ms at 8,192 streams). */
+template <u32 RING>
+struct Trip3Ring {
+    /* RING 128: 16 + RING + 32 bytes; RING 64: 32 bytes of slack, the ring, 52 behind it (every write has its twin 64 bytes
+       on or back: one select instead of two).  An odd number of words either way: the streams' rings start in different banks */
+    static constexpr u32 STRIDE = RING == 128u ? 180u : YT_RING_STRIDE;
+    static constexpr u32 FRONT = RING == 128u ? 16u : 32u;
+    static constexpr u32 NEAR = RING - 16u; /* a copy from less than this far back finds its source in the ring; one from further
+                                               back in memory, where all but the last CHUNK + 15 bytes are */
+};
+
+template <int S, u32 RING, u32 CHUNK>
 NOINL TripOut run_trip3_fn(TripIn a)
 {
+    static_assert(Trip3Ring<RING>::STRIDE <= YT_RING_ALLOC && CHUNK + 32u <= RING && (CHUNK & 15u) == 0, "ring layout");
+    constexpr u32 YT3_RING = RING, YT3_CHUNK = CHUNK, YT3_STRIDE = Trip3Ring<RING>::STRIDE, YT3_NEAR = Trip3Ring<RING>::NEAR;
     LAS TripLds<S> *wl = (LAS TripLds<S> *)a.wl;
     LAS const TripShared *ts = a.ts;
     const u32 slot = threadIdx.x & 63;
@@ -129,18 +150,30 @@ NOINL TripOut run_trip3_fn(TripIn a)
     u32 pn = 0; /* bytes of the piece asked for on the last trip */
     u32 po = 0; /* that piece is taken from the ring, at this offset + 1 (0: it lands in wl->piece) */
     const u32 base_lo = (u32)(uintptr_t)a.outp;
-    LAS u8 *const rb = (LAS u8 *)wl->ring + (slot & (S - 1)) * YT_RING_STRIDE + 32;
+    constexpr u32 RM = YT3_RING - 1;
+    LAS u8 *const rb = (LAS u8 *)wl->ring + (slot & (S - 1)) * YT3_STRIDE + Trip3Ring<RING>::FRONT;
+    /* where the second copy of sixteen bytes written at o goes: behind the ring's end for its first bytes, in front of
+       its start for a write that runs over the end, into the spare bytes otherwise */
+    auto ring_twin = [&](u32 o) __attribute__((always_inline)) -> u32 {
+        if constexpr (RING == 64u)
+            return o < 32 ? o + 64 : o - 64;
+        else
+            return o < 16 ? o + YT3_RING : o > YT3_RING - 16 ? o - YT3_RING : YT3_RING + 16;
+    };
     auto ring_put8 = [&](u32 o, u32 v) __attribute__((always_inline)) {
         rb[o] = (u8)v;
-        rb[o < 32 ? o + 64 : o - 64] = (u8)v;
+        if constexpr (RING == 64u)
+            rb[o < 32 ? o + 64 : o - 64] = (u8)v;
+        else
+            rb[o < 16 ? o + YT3_RING : YT3_RING + 16] = (u8)v;
     };
     {
-        ring_put8(63, a.p1);
-        ring_put8(62, a.p2);
+        ring_put8(RM, a.p1);
+        ring_put8(RM - 1, a.p2);
         u64 got0 = (u64)(a.outp - a.out);
-        u32 k = got0 < 48 ? (u32)got0 : 48u;
+        u32 k = got0 < YT3_NEAR ? (u32)got0 : YT3_NEAR;
         for (u32 j = 1; j <= k; j++)
-            ring_put8((0u - j) & 63, gld8(a.outp - j));
+            ring_put8((0u - j) & RM, gld8(a.outp - j));
     }
 
 #define WAITV(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory") /* at most n of the trip's three loads in flight */
@@ -267,7 +300,7 @@ NOINL TripOut run_trip3_fn(TripIn a)
 
         const bool dL = sd && st == YT_LIT;
         if (dL) { /* a literal: into the ring (yeast.c:1212-1223) */
-            ring_put8(((u32)(uintptr_t)op - base_lo) & 63, sym);
+            ring_put8(((u32)(uintptr_t)op - base_lo) & RM, sym);
             wn++;
             op++;
             insert--;
@@ -401,21 +434,18 @@ NOINL TripOut run_trip3_fn(TripIn a)
         if (pn) { /* the piece asked for on the last trip: sixteen bytes whatever pn, the excess lies where the next bytes go */
             const LAS u8 *pb = po ? (const LAS u8 *)(rb + (po - 1)) : (const LAS u8 *)&wl->piece[slot];
             const u32x4 pv = *(const LAS u32x4u *)pb;
-            const u32 o = (ac - pn) & 63;
+            const u32 o = (ac - pn) & RM;
             *(LAS u32x4u *)(rb + o) = pv;
-            *(LAS u32x4u *)(rb + (o < 32 ? o + 64 : o - 64)) = pv;
+            *(LAS u32x4u *)(rb + ring_twin(o)) = pv;
             wn += pn;
             pn = 0;
         }
-        if (wn >= 16) { /* at most 15 + 16 before: one chunk a trip keeps up */
-            const u32 co = (ac - wn) & 63; /* a multiple of 16 */
-#ifdef YT3_NT_STORE /* measurement aid: the output's lines are not kept in L2 */
-            typedef u32x4 __attribute__((aligned(16))) u32x4al;
-            __builtin_nontemporal_store(*(const LAS u32x4u *)(rb + co), (GAS u32x4al *)(op - wn));
-#else
-            gst128u(op - wn, *(const LAS u32x4u *)(rb + co));
-#endif
-            wn -= 16;
+        if (wn >= YT3_CHUNK) { /* at most YT3_CHUNK - 1 + 16 before: one chunk a trip keeps up */
+            const u32 co = (ac - wn) & RM; /* a multiple of YT3_CHUNK */
+#pragma unroll
+            for (u32 j = 0; j < YT3_CHUNK; j += 16)
+                gst128u(op - wn + j, *(const LAS u32x4u *)(rb + co + j));
+            wn -= YT3_CHUNK;
         }
 
         TMARK(3);
@@ -423,7 +453,7 @@ NOINL TripOut run_trip3_fn(TripIn a)
         {
             /* literal context -> table (context_id() yeast.c:698-755 through kctx; lit_map through lt),
                distance context -> table (yeast.c:1253-1257 through dt); the last two bytes are in the ring */
-            const u32 pp = *(const LAS u16u *)(rb + ((ac - 2) & 63)); /* p2 | p1 << 8 */
+            const u32 pp = *(const LAS u16u *)(rb + ((ac - 2) & RM)); /* p2 | p1 << 8 */
             const u32 f1 = ((const LAS u8 *)ts->kctx)[(kmode + (pp >> 8)) * 2];
             const u32 f2 = ((const LAS u8 *)ts->kctx)[(kmode + (pp & 255)) * 2 + 1];
             const u32 mi = nk == YT_DIST ? 64 * S + dcx * S : (f1 | f2) * S; /* dt lies behind lt */
@@ -509,9 +539,9 @@ NOINL TripOut run_trip3_fn(TripIn a)
         {
             const bool piece = crem != 0;
             const u32 back = (u32)(uintptr_t)op - (u32)(uintptr_t)csrc;
-            const bool nearc = piece && cD < 0x40000000u && back < 48; /* a dictionary word is never near */
+            const bool nearc = piece && cD < 0x40000000u && back < YT3_NEAR; /* a dictionary word is never near */
             lds_load16_nt(piece && !nearc ? csrc : wsb, lds_piece);
-            po = nearc ? (((u32)(uintptr_t)csrc - base_lo) & 63) + 1 : 0;
+            po = nearc ? (((u32)(uintptr_t)csrc - base_lo) & RM) + 1 : 0;
             pn = m;
             op += m;
             crem -= m;
@@ -551,16 +581,16 @@ NOINL TripOut run_trip3_fn(TripIn a)
         if (pn) {
             const LAS u8 *pb = po ? (const LAS u8 *)(rb + (po - 1)) : (const LAS u8 *)&wl->piece[slot];
             const u32x4 pv = *(const LAS u32x4u *)pb;
-            const u32 o = ((u32)(uintptr_t)op - base_lo - pn) & 63;
+            const u32 o = ((u32)(uintptr_t)op - base_lo - pn) & RM;
             *(LAS u32x4u *)(rb + o) = pv;
-            *(LAS u32x4u *)(rb + (o < 32 ? o + 64 : o - 64)) = pv;
+            *(LAS u32x4u *)(rb + ring_twin(o)) = pv;
             wn += pn;
             pn = 0;
         }
         const u32 co = (u32)(uintptr_t)op - base_lo - wn;
 #pragma clang loop unroll(disable) vectorize(disable)
         for (u32 j = 0; j < wn; j++)
-            gst8(op - wn + j, rb[(co + j) & 63]);
+            gst8(op - wn + j, rb[(co + j) & RM]);
     }
     TripOut o;
     o.outp = op;

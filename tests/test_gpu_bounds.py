@@ -44,7 +44,7 @@ if mode == "clean":
         dmg.append(bytes(b))
     cases = crafted + tdata + list(s4) + [s5[1]] + rnd + dmg + list(s2[:64])
     want = [H.oracle_yeast(s) for s in cases]
-    forms = [(64, 3, 1), (65, 3, 1), (1, 3, 1), (1, 3, 0), (1, 0, 1), (1, 2, 1), (16, 3, 1)]
+    forms = [(64, 3, 1), (65, 3, 1), (1, 3, 1), (1, 3, 0), (1, 4, 1), (1, 4, 0), (1, 0, 1), (1, 2, 1), (16, 3, 1)]
     for lanes, merge, half in forms:
         os.environ["YEAST_FORCE_LANES"] = str(lanes)
         os.environ["YEAST_MERGE"] = str(merge)

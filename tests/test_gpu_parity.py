@@ -62,10 +62,13 @@ KERNELS = [64, 65, 1]  # cooperative, wavefront per stream (LDS tables), one str
 
 # Every form of the decode path: the cooperative kernel, the wavefront-per-stream kernel, and the batch kernel
 # (one stream per lane) in the three forms the dispatcher uses by batch size -- (YEAST_MERGE, YEAST_HALF) =
-# (0, 1) plain loop, half-filled wavefronts (small batches); (2, 1) write-behind through the LDS ring, half-filled
-# (one round: what bench.py runs at 65,536 streams); (2, 0) the same in full wavefronts (more than one round).
-FORMS = [64, 65, (1, 0, 1), (1, 2, 1), (1, 2, 0), (1, 3, 1), (1, 3, 0)]
-FORM_IDS = ["coop64", "wave", "lean-plain", "lean-ring-half", "lean-ring-full", "lean-kinds-half", "lean-kinds-full"]
+# (0, 1) plain loop, half-filled wavefronts; (2, 1) round 2's write-behind through the LDS ring, half-filled; (2, 0) the same in
+# full wavefronts; (3, 1) the third loop form with 64-byte output chunks, half-filled (one round of a batch that fills the GPU:
+# what bench.py runs at 65,536 streams); (3, 0) the same in full wavefronts (more than one round); (4, 1) and (4, 0) the third
+# form with 16-byte chunks (what batches that do not fill the GPU get).
+FORMS = [64, 65, (1, 0, 1), (1, 2, 1), (1, 2, 0), (1, 3, 1), (1, 3, 0), (1, 4, 1), (1, 4, 0)]
+FORM_IDS = ["coop64", "wave", "lean-plain", "lean-ring-half", "lean-ring-full", "lean-kinds-half", "lean-kinds-full",
+            "lean-kinds16-half", "lean-kinds16-full"]
 
 
 def use_form(monkeypatch, form):
@@ -210,7 +213,7 @@ def test_randomly_assembled_streams(lanes, monkeypatch):
         assert r[1] == out, i
 
 
-@pytest.mark.parametrize("merge,half", [(1, 1), (2, 1), (2, 0), (3, 1), (3, 0)])
+@pytest.mark.parametrize("merge,half", [(1, 1), (2, 1), (2, 0), (3, 1), (3, 0), (4, 1), (4, 0)])
 def test_batch_kernel_with_one_store_per_command(monkeypatch, merge, half):
     # the forms of the batch kernel that gather the stores of the output (YEAST_MERGE 1: a copy's last piece and the
     # literals behind it stored as one unit, the form large batches get; 2: every byte through a ring in LDS and out in
@@ -412,7 +415,8 @@ def test_full_size_batch_properties():
     assert (r["check"] == want).all()
 
 
-@pytest.mark.parametrize("merge,half", [(2, 1), (2, 0), (3, 1), (3, 0)], ids=["ring-half", "ring-full", "kinds-half", "kinds-full"])
+@pytest.mark.parametrize("merge,half", [(2, 1), (2, 0), (3, 1), (3, 0), (4, 1)],
+                         ids=["ring-half", "ring-full", "kinds-half", "kinds-full", "kinds16-half"])
 def test_wavefronts_take_further_streams_when_theirs_are_done(merge, half, monkeypatch):
     # The batch kernel holds 65,536 streams at a time (256 per CU); a wavefront whose streams are all done takes the
     # next S from the queue (yeast_lane.hip k_decode_lean's loop).  72,000 short streams -- random plans whole and

@@ -29,7 +29,7 @@ for seed in range(first, first + seeds):
             extra.append((bytes(b), None))
         ss = ss + extra
     want = [H.oracle_yeast(s) for s, _ in ss]
-    for lanes, merge, half in ((1, 3, 1), (1, 3, 0), (1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 2, 0), (65, 3, 1), (64, 3, 1)):
+    for lanes, merge, half in ((1, 3, 1), (1, 3, 0), (1, 4, 1), (1, 4, 0), (1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 2, 0), (65, 3, 1), (64, 3, 1)):
         os.environ["YEAST_FORCE_LANES"] = str(lanes)
         os.environ["YEAST_MERGE"] = str(merge)
         os.environ["YEAST_HALF"] = str(half)
