@@ -443,8 +443,14 @@ NOINL TripOut run_trip3_fn(TripIn a)
         if (wn >= YT3_CHUNK) { /* at most YT3_CHUNK - 1 + 16 before: one chunk a trip keeps up */
             const u32 co = (ac - wn) & RM; /* a multiple of YT3_CHUNK */
 #pragma unroll
-            for (u32 j = 0; j < YT3_CHUNK; j += 16)
+            for (u32 j = 0; j < YT3_CHUNK; j += 16) {
+#ifdef YT3_NT_STORE /* measurement aid: the output's lines are not kept in L2 */
+                typedef u32x4 __attribute__((aligned(16))) u32x4al;
+                __builtin_nontemporal_store(*(const LAS u32x4u *)(rb + co + j), (GAS u32x4al *)(op - wn + j));
+#else
                 gst128u(op - wn + j, *(const LAS u32x4u *)(rb + co + j));
+#endif
+            }
             wn -= YT3_CHUNK;
         }
 
