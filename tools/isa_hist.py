@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/isa_hist.py -- instruction histogram of the batch kernel's command loop, from the compiler's own listing.
 
-    python3 tools/isa_hist.py [function-substring ...]      (default: the third loop form and round 2's ring form)
+    python3 tools/isa_hist.py [function-substring ...]      (default: the third loop form in its two settings and round 2's ring form)
 
 Compiles brotli_amd/csrc/yeast_lane.hip to gfx950 assembly with the product's flags (hipcc -S, device only; no GPU
 needed), finds in each named function its largest loop (label ... backward branch to that label) and counts the
@@ -129,8 +129,9 @@ def analyse(lines, lo, hi):
 
 
 def main():
-    want = sys.argv[1:] or ["run_trip3_fnILi32E", "run_trip_fnILi544E"]
-    titles = {"run_trip3_fnILi32E": "run_trip3_fn<32>: the third loop form (round 3, the bench's kernel)",
+    want = sys.argv[1:] or ["run_trip3_fnILi32ELj128E", "run_trip3_fnILi32ELj64E", "run_trip_fnILi544E"]
+    titles = {"run_trip3_fnILi32ELj128E": "run_trip3_fn<32, 128, 64>: the third loop form with 64-byte output chunks (round 3, the bench's kernel)",
+              "run_trip3_fnILi32ELj64E": "run_trip3_fn<32, 64, 16>: the third loop form with 16-byte chunks (batches that do not fill the GPU)",
               "run_trip_fnILi544E": "run_trip_fn<32 | ring>: round 2's write-behind loop (YEAST_MERGE=2)"}
     lines = listing()
     fns = functions(lines)
