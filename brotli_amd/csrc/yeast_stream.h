@@ -692,6 +692,15 @@ DEV u32 metablock(Ctx &c, u32 sub)
     const u64 *cmd_tab = c.sh->cmd;
 
     if (!FLAT) {
+        /* The copies of a meta-block WITHOUT a literal context map leave p1/p2 alone (emit_copy, emit_dict), so when such
+           a block ends in a copy, the first literals of a following block WITH a map would take their context from stale
+           bytes (found by tools/soak_random.py on a damaged stream, tests/golden/soak_3034_770.bin: intact plans end
+           every block in literals).  The last two bytes are in memory (compare mode: the expected data, equal so far). */
+        if (ctx) {
+            u64 got = got_of(c);
+            c.p1 = got >= 1 ? gld8(c.outp - 1) : 0;
+            c.p2 = got >= 2 ? gld8(c.outp - 2) : 0;
+        }
         /* ---- command loop: yeast.c:1166-1295 ---- */
         do {
             if (c.I.num > 1) {

@@ -213,6 +213,24 @@ def test_randomly_assembled_streams(lanes, monkeypatch):
         assert r[1] == out, i
 
 
+@pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
+def test_stream_found_by_the_soak(form, monkeypatch):
+    # tools/soak_random.py, seed 3034, stream 770 (a damaged copy): a meta-block without a literal context map ends in a
+    # copy, the next one has a map -- its first literal contexts are the bytes that copy wrote.  The cooperative kernel
+    # kept p1/p2 only while a map was in use and decoded 803 bytes wrongly (the reference: rc 3, got 2218, used 202).
+    # Beside it: intact streams of the same shape from the random plans (half of the blocks that another follows end
+    # in a copy).
+    import random_plans as R
+    use_form(monkeypatch, form)
+    s = open(os.path.join(H.GOLD, "soak_3034_770.bin"), "rb").read()
+    cases = [s] + [x for x, _ in R.streams(120, 770)]
+    want = [H.oracle_yeast(x) for x in cases]
+    assert want[0][:3] == (3, 2218, 202)
+    for i, (w, r) in enumerate(zip(want, ba.yeast_batch(cases))):
+        assert (r[0], r[2], r[3]) == w[:3], i
+        assert r[1] == w[3], i
+
+
 @pytest.mark.parametrize("merge,half", [(1, 1), (2, 1), (2, 0), (3, 1), (3, 0), (4, 1), (4, 0)])
 def test_batch_kernel_with_one_store_per_command(monkeypatch, merge, half):
     # the forms of the batch kernel that gather the stores of the output (YEAST_MERGE 1: a copy's last piece and the
