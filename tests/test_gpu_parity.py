@@ -107,6 +107,20 @@ def test_crafted_streams_through_every_kernel(lanes, monkeypatch):
 
 
 @pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
+def test_testdata_corpus_through_every_form(form, monkeypatch):
+    # the reference's own corpus (real encoder output: several meta-blocks per file, ring-buffer and implicit distances
+    # that reach across them, blocks that end in copies) as ONE batch through every form of the decode path -- the
+    # default dispatch gives so few streams to the wavefront-per-stream kernel only
+    use_form(monkeypatch, form)
+    idx = H.load_json("testdata.json")
+    pairs = list(H.testdata_pairs())
+    res = ba.yeast_batch([comp for _, comp, _ in pairs])
+    for (name, comp, orig), r in zip(pairs, res):
+        assert (r[0], r[2], r[3]) == (0, idx[name]["got"], idx[name]["used"]), name
+        assert r[1] == orig, name
+
+
+@pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
 def test_misc_encoder_parameters(form, monkeypatch):
     # window bits 10..24, qualities 0..10, NPOSTFIX/NDIRECT != 0 (unpinned by testdata/)
     use_form(monkeypatch, form)
