@@ -119,6 +119,25 @@ def main():
                 if (r[0], r[2], r[3], r[1]) != (w[0], w[1], w[2], w[3]):
                     bad += 1
                     print("MISMATCH seed %d stream %d lanes %d merge %d half %d: gpu %s oracle %s" % (seed, i, lanes, merge, half, (r[0], r[2], r[3]), w[:3]), flush=True)
+        # compare mode (yeast(cmp = 1): the cooperative kernel's other instantiation) on the intact streams: the exact data, a
+        # flipped byte, data cut short and data with a tail; (rc, got, used) as the restatement reports them
+        for k in ("YEAST_FORCE_LANES", "YEAST_MERGE", "YEAST_HALF"):
+            os.environ.pop(k, None)
+        for i in range(0, per, 3):
+            s, data = ss[i], want[i][3]
+            if want[i][0] != 0:
+                continue
+            exps = [data, data + b"x"]
+            if len(data) > 1:
+                e = bytearray(data)
+                e[rng.randrange(len(e))] ^= 0x10
+                exps += [bytes(e), data[:rng.randrange(0, len(data))]]
+            for e in exps:
+                rc, out, got, used = ba.yeast(s, e)
+                w = H.oracle_yeast(s, e)
+                if (rc, got, used) != w[:3]:
+                    bad += 1
+                    print("MISMATCH (compare mode) seed %d stream %d: gpu %s oracle %s" % (seed, i, (rc, got, used), w[:3]), flush=True)
         print("seed %d: %d streams (%d bytes out), encode+oracle %.1f s, gpu %.1f s" % (seed, len(ss), sum(w[1] for w in want), t1 - t0, time.time() - t1), flush=True)
     print("mismatches:", bad)
     sys.exit(1 if bad else 0)
