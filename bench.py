@@ -96,6 +96,18 @@ def cpu_baseline(streams, order, cores, sample):
                       % (sample, total, cores)}
 
 
+def kernel_sources_hash():
+    """sha256 over the kernel sources: figures measured on another version of the kernels (profiles/hbm_traffic.json,
+    profiles/r03/ceilings.json carry the hash they were measured on) are not quoted as this run's."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "brotli_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "brotli_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
     """HBM-to-HBM copy rate on this GPU (bytes read + bytes written per second), the practical
     ceiling beside the 8 TB/s spec figure (SURVEY 8d side figure)."""
@@ -266,11 +278,14 @@ def main():
     # HBM bytes per launch from the PMC passes (tools/prof_summary.py writes the file).  Only quoted when it was
     # measured on this batch size AND on the kernel that ran just now: a figure of another kernel is no figure.
     traffic, traffic_note = None, None
+    src_hash = kernel_sources_hash()
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf):
         try:
             t = json.load(open(tf))
-            if t.get("streams") == n and kernel and kernel in str(t.get("kernel", "")):
+            if t.get("streams") == n and kernel and kernel in str(t.get("kernel", "")) and t.get("csrc") != src_hash:
+                traffic_note = "profiles/hbm_traffic.json was measured on kernel sources %s, these are %s: not quoted" % (t.get("csrc"), src_hash)
+            elif t.get("streams") == n and kernel and kernel in str(t.get("kernel", "")):
                 traffic = t.get("bytes_per_launch")
                 traffic_note = {k: t[k] for k in ("fetch_bytes", "write_bytes", "fetch_factor", "source") if k in t}
             elif t.get("streams") == n:
@@ -287,7 +302,7 @@ def main():
     if os.path.exists(cf):
         try:
             c = json.load(open(cf))
-            if c.get("streams") == n and kernel and kernel in str(c.get("kernel", "")):
+            if c.get("streams") == n and kernel and kernel in str(c.get("kernel", "")) and c.get("csrc") == src_hash:
                 hl, it = c["hbm_lines"], c["issue"]
                 b1 = hl["lines_per_launch"] / hl["ceiling_lines_per_s"] * 1e3
                 b2 = it["longest_stream_trips"] * it["instructions_per_trip"] * it["cycles_per_instruction"] / (it["clock_ghz"] * 1e9) * 1e3

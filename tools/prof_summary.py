@@ -30,10 +30,19 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
             tot[name] = sum(float(r["Counter_Value"]) for r in rows) / len(rows) * 1024.0
             kname = re.sub(r"^void |\(.*$", "", rows[0]["Kernel_Name"])
 if len(tot) == 2 and len(sys.argv) > 2:
-    out = {"streams": int(sys.argv[2]), "kernel": kname, "fetch_bytes": tot["FETCH_SIZE"], "fetch_factor": 1.0,
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    out = {"streams": int(sys.argv[2]), "kernel": kname, "csrc": bench.kernel_sources_hash(), "fetch_bytes": tot["FETCH_SIZE"], "fetch_factor": 1.0,
            "fetch_bytes_if_streaming_x2": 2 * tot["FETCH_SIZE"],
            "write_bytes": tot["WRITE_SIZE"], "bytes_per_launch": tot["FETCH_SIZE"] + tot["WRITE_SIZE"],
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB x 1024, mean over launches; FETCH_SIZE x 1: "
                      "calibrated on scattered 2- and 16-byte loads (profiles/r03/fetch_calibration.txt)"}
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "hbm_traffic.json"), "w"), indent=1)
+    # the ceilings file follows the same counters (lines = bytes / 64); its trip and instruction counts are edited by hand
+    cf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03", "ceilings.json")
+    if os.path.exists(cf):
+        c = json.load(open(cf))
+        c["kernel"], c["streams"], c["csrc"] = kname, int(sys.argv[2]), out["csrc"]
+        c["hbm_lines"]["lines_per_launch"] = out["bytes_per_launch"] / 64.0
+        json.dump(c, open(cf, "w"), indent=1)
     print("hbm_traffic.json:", out)
