@@ -138,7 +138,13 @@ struct TripOut {
 DEV void lds_load4(const u8 *sbase, u32 voff, u32 lds)
 {
     voff = YSB(sbase + (u64)voff, 4) ? voff : 0u; /* bounds-checked build: a load out of range reads the base instead */
+#ifdef YT_ENT_HINT /* measurement builds: the table entry's load with a cache hint (nt, sc0, sc1 ...) */
+#define YT_STR2(x) #x
+#define YT_STR(x) YT_STR2(x)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 " YT_STR(YT_ENT_HINT) : : "v"(voff), "s"(sbase), "s"(lds) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds) : "memory");
+#endif
 }
 DEV void lds_load16(const u8 *src, u32 lds)
 {

@@ -224,7 +224,11 @@ NOINL TripOut run_trip3_fn(TripIn a)
     auto request = [&](bool on) __attribute__((always_inline)) {
         lds_load4(wsb, on ? la + (__builtin_amdgcn_ubfe(lo, 0, lw) << 1) : 0u, lds_ent);
         treq = nq <= 4 && st != YT_END && endrel > nq * 32;
+#ifdef YT3_TOP_NT /* measurement aid: the input words not kept in L2 */
+        lds_load16_nt(treq ? ip : wsb, lds_top);
+#else
         lds_load16(treq ? ip : wsb, lds_top);
+#endif
     };
 
     enter(true, YT_CMD, offI, left0, left1, left2);
