@@ -101,10 +101,14 @@ def kernel_sources_hash():
     profiles/r03/ceilings.json carry the hash they were measured on) are not quoted as this run's."""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "brotli_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "brotli_amd", "csrc", "*.hip"))):
+        text = open(f, "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)  # comments and layout do not change the kernels
+        text = re.sub(r"//[^\n]*", " ", text)
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

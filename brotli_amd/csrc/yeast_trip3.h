@@ -1,8 +1,9 @@
 /*
  * yeast_trip3.h -- the command loop of the batch kernel in its third form (included by yeast_trip.h; reference:
  * the loop of yeast.c:1166-1295).  Same trip as run_trip_fn's write-behind form -- one prefix-code symbol per
- * stream and trip, three loads that land in LDS behind counted waits, every output byte through a 64-byte ring in
- * LDS and out in complete 16-byte chunks -- written for fewer instructions per trip:
+ * stream and trip, three loads that land in LDS behind counted waits, every output byte through a ring in LDS and out
+ * in complete chunks (a 128-byte ring and whole 64-byte lines, or 64 bytes and 16-byte chunks: Trip3Ring below) --
+ * written for fewer instructions per trip:
  *
  *   - what a symbol kind needs is done under that kind's lanes only (one of: literal, insert-and-copy symbol,
  *     distance symbol, copy set-up), and each kind says what the stream decodes next (nk), instead of every step
@@ -12,8 +13,9 @@
  *   - a copy of several pieces is a state of its own (HOLD): the next command's symbol is asked for with the
  *     copy's last piece, and no entry is held in a register meanwhile;
  *   - the last two bytes (literal context) are one unaligned 16-bit read from the ring, whatever wrote them;
- *   - a copy from less than 48 bytes back reads the ring when its piece is appended, a trip later (nothing
- *     writes the ring in between), so no staging slot and no branch at set-up;
+ *   - a copy from close behind the output (less than 112 bytes with the 128-byte ring, 48 with the 64-byte one) reads the
+ *     ring when its piece is appended, a trip later (nothing writes the ring in between), so no staging slot and no
+ *     branch at set-up;
  *   - streams without a literal or distance context map get maps filled with their one table, so the lookup is
  *     the same for all.
  */
