@@ -57,6 +57,9 @@ typedef struct {
     const u8 *xforms;    /* 121 x 20-byte transform records */
     const u8 *xdict;     /* every transform of every dictionary word (built on the device at start-up) */
     const u32 *xdict_base; /* [121][21]: byte offset in xdict of (transform, word length 4..24), entries back to back */
+    const u32 *maxlen;   /* batch kernel: the longest stream's compressed bytes (written by the hand-out order's kernels) */
+    u32 delay;           /* batch kernel, one round with every block resident: a wavefront whose streams are shorter than the
+                            longest begins that much later, in ns per byte of difference (0 = at once): see yeast_lane.hip */
     u32 rootcaps;        /* root table widths: other | literal << 8 | insert-and-copy << 16 | distance << 24;
                             0 = 8 bits everywhere (the only setting of the kernels other than the lean one) */
 } ys_params;

@@ -35,7 +35,7 @@ int ys_launch_decode_static(const ys_params *p, int device, void *stream);
 int ysl_upload_constants(const u8 *lut768);
 int ysl_expand_dict(const u8 *dict, const u8 *xforms, const u32 *base, u8 *xdict, void *stream);
 int ysl_launch(const ys_params *p, int half, int merge, unsigned streams, void *stream);
-int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *order, void *stream);
+int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *maxlen, u32 *order, void *stream);
 int ysw_upload_constants(const u8 *lut768);
 unsigned ysw_shared_bytes(void);
 int ysw_launch(const ys_params *p, unsigned slot_entries, unsigned rootcaps, unsigned blocks, void *stream);
@@ -332,7 +332,7 @@ static const char *const KNOB_NAMES[] = {"YEAST_LANES", "YEAST_WAVES_PER_CU", "Y
                                          "YEAST_WS_KB", "YEAST_LEAN_ROOT_LIT", "YEAST_LEAN_ROOT_IAC",
                                          "YEAST_LEAN_ROOT_DIST", "YEAST_SORT", "YEAST_DEBUG", "YEAST_HOST_THREADS",
                                          "YEAST_FORCE_LANES", "YEAST_PRIO", "YEAST_HOST_BUDGET_MB", "YEAST_MERGE", "YEAST_PAIR",
-                                         "YEAST_HOST_FLOOR", "YEAST_D2H_PIN_KB", "YEAST_BOUNDS_SHRINK", "YEAST_CHUNK64_FROM"};
+                                         "YEAST_HOST_FLOOR", "YEAST_D2H_PIN_KB", "YEAST_BOUNDS_SHRINK", "YEAST_CHUNK64_FROM", "YEAST_DELAY"};
 enum { KNOBS = sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]) };
 static int g_knob_val[KNOBS];
 static bool g_knob_set[KNOBS];
@@ -625,15 +625,19 @@ static int enqueue_impl(Device &d, const u8 *src, const u64 *soff, u8 *dst, cons
         YSB_ARM();
         if (env_int("YEAST_SORT", 1)) { /* hand the streams out by size class, longest first (yeast_lane.hip) */
             u32 *order = p.retry_list + n;
-            e = ysl_order(soff, (unsigned)n, (u32 *)d.ctr.p + 4, order, st);
+            e = ysl_order(soff, (unsigned)n, (u32 *)d.ctr.p + 4, (u32 *)d.ctr.p + 3, order, st);
+            p.maxlen = (u32 *)d.ctr.p + 3;
             if (e)
                 return fail("hand-out order launch", (hipError_t)e);
             p.order = order;
         }
         p.debug = (u32)env_int("YEAST_DEBUG", 0);
         /* two blocks per CU, all resident at once, sorted hand-out: pair long with short on a SIMD (yeast_lane.hip) */
-        if (p.order && blocks_per_cu == 2 && blocks == 2 * (unsigned)d.cus && (blocks & 1) == 0 && env_int("YEAST_PAIR", 1))
-            p.debug |= 2; /* (issue priority for the wavefronts with the long streams on top of it: no difference, 46.5 ms either way) */
+        if (p.order && blocks_per_cu == 2 && blocks == 2 * (unsigned)d.cus && (blocks & 1) == 0 && env_int("YEAST_PAIR", 1)) {
+            p.delay = (u32)env_int("YEAST_DELAY", 300); /* ns per byte a wavefront's longest stream lacks to the batch's longest */
+            p.debug |= 2;
+        }
+        /* (issue priority for the wavefronts with the long streams on top of the pairing: no difference, 46.5 ms either way) */
         /* batches that fill the GPU: the loop that gathers its stores (yeast_trip.h; YEAST_MERGE 2: every output byte
            through a ring in LDS and out in complete 16-byte chunks, 47.6 ms against 57.4 at 65,536 streams; 1: one store
            per command, 52.6 ms; 0: the plain loop, faster at 32,768 streams and fewer, where a wavefront has its SIMD to
@@ -648,6 +652,7 @@ static int enqueue_impl(Device &d, const u8 *src, const u64 *soff, u8 *dst, cons
         e = ysl_launch(&p, half, merge, groups, st);
         p.order = nullptr;
         p.debug = 0;
+        p.delay = 0;
     }
     else {
         snprintf(t_kernel, sizeof(t_kernel), "k_decode<%d, %s>", lanes, cmp ? "true" : "false");

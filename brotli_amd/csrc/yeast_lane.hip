@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
        takes it from the end, so the wavefront with the longest streams shares its SIMD with the one that has the shortest
        and has it to itself soonest.  Later rounds, if any, take what is left in order. */
     bool first = (p.debug & 2) != 0 && !p.retry;
+    bool delayed = first;
     const u32 nblk = gridDim.x;
     for (;;) {
         u32 base = 0;
@@ -57,11 +58,39 @@ __global__ __launch_bounds__(256, (64 / S) > YS_MAX_OCC ? YS_MAX_OCC : 64 / S) v
         if (base >= limit)
             break;
         u32 job = base + slot;
-        if (slot < S && job < limit) {
+        const bool mine = slot < S && job < limit;
+        if (mine) {
             if (p.retry)
                 job = p.retry_list[job];
             else if (p.order)
                 job = p.order[job];
+        }
+        /* Delayed start (one round, every block resident).  The launch lasts as long as the wavefronts with the longest
+           streams; the wavefronts that share their SIMDs hold the shortest and have time to spare at the end.  They spend
+           a little of it here, before they begin: the longest then parse their headers (3.3 ms alone, 3.8 ms beside
+           another header on the SIMD) and make their first trips with the SIMD and the memory system less busy.  A stream's
+           work follows its compressed size, so the wait is proportional to what the wavefront's longest stream lacks to
+           the batch's longest -- nothing for a batch of equal streams -- and never more than 4 ms, about a header's
+           time: a wavefront whose size did not predict its work extends the launch by that at most.  It decides when a
+           stream is decoded, never how (44.2 -> 43.7 ms at 65,536 streams; profiles/r03/pace_sweep.txt). */
+        if (delayed && p.delay) {
+            u64 len = mine ? p.src_off[job + 1] - p.src_off[job] : 0;
+            u32 l32 = len > 0x7fffffffull ? 0x7fffffffu : (u32)len, lw = 0;
+            for (u64 todo = __ballot(1); todo; todo &= todo - 1) {
+                u32 v = (u32)__builtin_amdgcn_readlane((int)l32, (int)__builtin_ctzll(todo));
+                lw = v > lw ? v : lw;
+            }
+            const u32 lmax = __builtin_amdgcn_readfirstlane(*p.maxlen);
+            if (lmax > lw) {
+                u64 ticks = (u64)(lmax - lw) * p.delay / 10; /* s_memrealtime counts 100 MHz */
+                ticks = ticks > 400000 ? 400000 : ticks;
+                const u64 t0 = __builtin_amdgcn_s_memrealtime();
+                while (__builtin_amdgcn_s_memrealtime() - t0 < ticks)
+                    __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        delayed = false;
+        if (mine) {
             decode_stream<1, false, S | (UNIT << 8)>(p, job, ws, shp, 0, &wlds[lane >> 6], tsp, wbase);
         }
     }
@@ -109,19 +138,27 @@ DEV u32 order_bin(u64 len)
 }
 /* both counting kernels count inside the block first (LDS atomics) and touch a global counter once
    per block and class: 65,536 streams fall into a few dozen classes */
-__global__ __launch_bounds__(256) void k_order_hist(const u64 *src_off, u32 n, u32 *bins)
+__global__ __launch_bounds__(256) void k_order_hist(const u64 *src_off, u32 n, u32 *bins, u32 *maxlen)
 {
     __shared__ u32 cnt[YS_ORDER_BINS];
+    __shared__ u32 longest;
+    if (threadIdx.x == 0)
+        longest = 0;
     for (u32 k = threadIdx.x; k < YS_ORDER_BINS; k += 256)
         cnt[k] = 0;
     __syncthreads();
     u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n)
-        atomicAdd(cnt + order_bin(src_off[i + 1] - src_off[i]), 1u);
+    if (i < n) {
+        u64 len = src_off[i + 1] - src_off[i];
+        atomicAdd(cnt + order_bin(len), 1u);
+        atomicMax(&longest, len > 0x7fffffffull ? 0x7fffffffu : (u32)len);
+    }
     __syncthreads();
     for (u32 k = threadIdx.x; k < YS_ORDER_BINS; k += 256)
         if (cnt[k])
             atomicAdd(bins + k, cnt[k]);
+    if (threadIdx.x == 0)
+        atomicMax(maxlen, longest);
 }
 __global__ __launch_bounds__(YS_ORDER_BINS) void k_order_scan(u32 *bins)
 {
@@ -157,12 +194,12 @@ __global__ __launch_bounds__(256) void k_order_scatter(const u64 *src_off, u32 n
         order[cnt[b] + rank] = i;
 }
 
-/* bins: YS_ORDER_BINS zeroed counters; order: n entries */
-extern "C" int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *order, void *stream)
+/* bins: YS_ORDER_BINS zeroed counters; maxlen: a zeroed counter (the longest stream's bytes); order: n entries */
+extern "C" int ysl_order(const u64 *src_off, unsigned n, u32 *bins, u32 *maxlen, u32 *order, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     unsigned blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_order_hist, dim3(blocks), dim3(256), 0, st, src_off, n, bins);
+    hipLaunchKernelGGL(k_order_hist, dim3(blocks), dim3(256), 0, st, src_off, n, bins, maxlen);
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(YS_ORDER_BINS), 0, st, bins);
     hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(256), 0, st, src_off, n, bins, order);
     return (int)hipGetLastError();
