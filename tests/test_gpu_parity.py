@@ -447,14 +447,16 @@ def test_full_size_batch_properties():
     assert (r["check"] == want).all()
 
 
-@pytest.mark.parametrize("merge,half", [(2, 1), (2, 0), (3, 1), (3, 0), (4, 1)],
-                         ids=["ring-half", "ring-full", "kinds-half", "kinds-full", "kinds16-half"])
-def test_wavefronts_take_further_streams_when_theirs_are_done(merge, half, monkeypatch):
+@pytest.mark.parametrize("merge,half,n", [(2, 1, 72000), (2, 0, 72000), (3, 1, 72000), (3, 0, 72000), (4, 1, 72000), (3, 1, 65536)],
+                         ids=["ring-half", "ring-full", "kinds-half", "kinds-full", "kinds16-half", "kinds-half-one-round"])
+def test_wavefronts_take_further_streams_when_theirs_are_done(merge, half, n, monkeypatch):
     # The batch kernel holds 65,536 streams at a time (256 per CU); a wavefront whose streams are all done takes the
     # next S from the queue (yeast_lane.hip k_decode_lean's loop).  72,000 short streams -- random plans whole and
     # damaged, the crafted good and bad streams -- force that in both ring forms (S = 32 and S = 64); every record
     # and every output byte against the CPU restatement.  The reused wavefront inherits LDS (ring, maps, landing
-    # slots) and workspace from the streams before, failed ones among them.
+    # slots) and workspace from the streams before, failed ones among them.  The last case is exactly one round (65,536
+    # streams, every block resident): the static first hand-out that pairs long with short on a SIMD and the delayed
+    # start of the wavefronts with shorter streams, on streams of every size, failed ones among them.
     import random_plans as R
     import torch
     from brotli_amd.device import DeviceBatch
@@ -489,7 +491,6 @@ def test_wavefronts_take_further_streams_when_theirs_are_done(merge, half, monke
             need[j] = int(pr["check"][j]) + 40
     keep = [j for j in range(len(ss)) if need[j] <= (1 << 18) and pr["rc"][j] != 5]
     assert len(keep) > 300
-    n = 72000
     pick = np.array(keep)[np.random.RandomState(9 + half).randint(0, len(keep), size=n)]
     caps = [need[j] for j in pick]
     batch = DeviceBatch([ss[j] for j in pick], caps, align=16)
